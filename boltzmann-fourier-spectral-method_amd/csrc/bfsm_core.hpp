@@ -1,0 +1,482 @@
+// bfsm_core.hpp -- workgroup-level bodies of the gfx950 kernels of the Fourier-spectral Boltzmann collision
+// operator (replaces the cuFFT plans + the 6 CUDA kernels of Collisions/CUDABoltzmannOperator.cu:119-220 and
+// Collisions/BoltzmannCUDAKernels.cu:4-177 with a fused 3-kernel-per-chunk pipeline).
+//
+// Every body is a function template over a small execution context `Ctx` (thread id, block id, LDS base,
+// workgroup barrier).  bfsm_hip.hip instantiates them with the device context inside __global__ kernels;
+// tests/emu instantiates the same code with a host lock-step context so the index algebra is unit-tested on CPU.
+//
+// Data layout conventions (N = Nvx = Nvy = Nvz, G = N^3, complex = interleaved (re,im) of T):
+//   physical space   [x][y][z]      z contiguous  (the reference's idx3 = (i*Nvy + j)*Nvz + k)
+//   spectral space   [lx][lz][ly]   ly contiguous ("spectral-transposed": every 2-D plane transform transposes,
+//                                   so no pass ever needs a strided global access)
+//   Fourier modes in FFT order 0..N/2-1, -N/2..-1 (FFTWBoltzmannOperator.cpp:50-57)
+//
+// 1-D transforms: a line of N points is held by T = N/E threads, E points each, thread u owning the points
+// u + T*m (m < E).  One Stockham step = radix-E butterflies in registers, twiddle, exchange through LDS,
+// radix-T butterflies; the result is again distributed as u + T*m, so passes chain without re-distribution.
+// Lanes always run along the axis that is NOT being transformed, so LDS exchanges are conflict-free and every
+// global access is a run of N contiguous elements.
+#pragma once
+#include <stdint.h>
+
+#ifndef BFSM_HD
+#define BFSM_HD __device__ __forceinline__
+#endif
+
+namespace bfsm {
+
+template <typename T>
+struct alignas(2 * sizeof(T)) cx {
+    T x, y;
+};
+
+template <typename T> BFSM_HD cx<T> cadd(cx<T> a, cx<T> b) { return {a.x + b.x, a.y + b.y}; }
+template <typename T> BFSM_HD cx<T> csub(cx<T> a, cx<T> b) { return {a.x - b.x, a.y - b.y}; }
+template <typename T> BFSM_HD cx<T> cmul(cx<T> a, cx<T> b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+// a * conj(b)
+template <typename T> BFSM_HD cx<T> cmulc(cx<T> a, cx<T> b) { return {a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y}; }
+// multiply by SGN * i
+template <int SGN, typename T> BFSM_HD cx<T> rot90(cx<T> a) {
+    if (SGN > 0) return {-a.y, a.x};
+    return {a.y, -a.x};
+}
+
+// cos / sin of 2*pi*j/16, folded at compile time after unrolling
+BFSM_HD constexpr double cos16(int j) {
+    switch (j & 15) {
+        case 0: return 1.0;
+        case 1: return 0.92387953251128673848;
+        case 2: return 0.70710678118654752440;
+        case 3: return 0.38268343236508977173;
+        case 4: return 0.0;
+        case 5: return -0.38268343236508977173;
+        case 6: return -0.70710678118654752440;
+        case 7: return -0.92387953251128673848;
+        case 8: return -1.0;
+        case 9: return -0.92387953251128673848;
+        case 10: return -0.70710678118654752440;
+        case 11: return -0.38268343236508977173;
+        case 12: return 0.0;
+        case 13: return 0.38268343236508977173;
+        case 14: return 0.70710678118654752440;
+        default: return 0.92387953251128673848;
+    }
+}
+BFSM_HD constexpr double sin16(int j) { return cos16(j + 12); }  // sin(a) = cos(a - pi/2) = cos(a + 3pi/2)
+
+// In-register DFT of R points, natural order in and out, unnormalised.
+// SGN = -1: forward (exp(-i...)), SGN = +1: backward -- the FFTW_FORWARD / FFTW_BACKWARD convention.
+template <int R, int SGN, typename T>
+struct SmallDft {
+    static BFSM_HD void run(cx<T>* a) {
+        static_assert(R == 4 || R == 8 || R == 16, "radix");
+        cx<T> e[R / 2], o[R / 2];
+#pragma unroll
+        for (int k = 0; k < R / 2; ++k) {
+            e[k] = a[2 * k];
+            o[k] = a[2 * k + 1];
+        }
+        SmallDft<R / 2, SGN, T>::run(e);
+        SmallDft<R / 2, SGN, T>::run(o);
+#pragma unroll
+        for (int k = 0; k < R / 2; ++k) {
+            cx<T> t;
+            const int j = k * (16 / R);  // angle 2*pi*k/R in sixteenths of a turn
+            if (j == 0) {
+                t = o[k];
+            } else if (j == 4) {
+                t = rot90<SGN>(o[k]);
+            } else {
+                const T c = (T)cos16(j), s = (T)(SGN * sin16(j));
+                t = {o[k].x * c - o[k].y * s, o[k].x * s + o[k].y * c};
+            }
+            a[k] = cadd(e[k], t);
+            a[k + R / 2] = csub(e[k], t);
+        }
+    }
+};
+template <int SGN, typename T>
+struct SmallDft<2, SGN, T> {
+    static BFSM_HD void run(cx<T>* a) {
+        const cx<T> t = a[0];
+        a[0] = cadd(t, a[1]);
+        a[1] = csub(t, a[1]);
+    }
+};
+template <int SGN, typename T>
+struct SmallDft<1, SGN, T> {
+    static BFSM_HD void run(cx<T>*) {}
+};
+
+// Compile-time geometry of an N-point line: E points per thread, T threads per line.
+template <int N> struct Geo;
+template <> struct Geo<16>  { static constexpr int E = 4,  T = 4; };
+template <> struct Geo<32>  { static constexpr int E = 8,  T = 4; };
+template <> struct Geo<64>  { static constexpr int E = 8,  T = 8; };
+template <> struct Geo<128> { static constexpr int E = 16, T = 8; };
+
+template <int N>
+struct Wg {
+    static constexpr int E = Geo<N>::E;
+    static constexpr int T = Geo<N>::T;
+    static constexpr int Q = E / T;           // radix-T sub-transforms per thread in the second step
+    static constexpr int THREADS = N * T;     // one N x N tile per workgroup
+    static constexpr int LS = N + 1;          // LDS row stride (elements); odd => transposed reads conflict-free
+    static constexpr int LDS_ELEMS = N * LS;
+    static_assert(E * T == N && Q * T == E, "geometry");
+};
+
+// ---- one distributed 1-D transform -------------------------------------------------------------------------
+// v[m] = x[u + T*m] on entry, X[u + T*m] on exit.  lds rows are indexed by position along the line, columns
+// by the lane index p.  tw[n] = exp(-2*pi*i*n/N) (forward table; conjugated for SGN = +1).
+template <int N, int SGN, typename T, class Ctx>
+BFSM_HD void fft_line(cx<T>* v, cx<T>* lds, int p, int u, const cx<T>* __restrict__ tw, Ctx& ctx) {
+    constexpr int E = Wg<N>::E, TT = Wg<N>::T, Q = Wg<N>::Q, LS = Wg<N>::LS;
+    SmallDft<E, SGN, T>::run(v);
+#pragma unroll
+    for (int k1 = 1; k1 < E; ++k1) {
+        const cx<T> w = tw[u * k1];
+        v[k1] = (SGN < 0) ? cmul(v[k1], w) : cmulc(v[k1], w);
+    }
+    ctx.sync();  // previous readers of lds are done
+#pragma unroll
+    for (int k1 = 0; k1 < E; ++k1) lds[(k1 * TT + u) * LS + p] = v[k1];
+    ctx.sync();
+    cx<T> w2[E];
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int uu = 0; uu < TT; ++uu) w2[q * TT + uu] = lds[((u + TT * q) * TT + uu) * LS + p];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) SmallDft<TT, SGN, T>::run(w2 + q * TT);
+    // output index k1 + E*k2 with k1 = u + T*q  ==  u + T*(q + Q*k2)
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int k2 = 0; k2 < TT; ++k2) v[q + Q * k2] = w2[q * TT + k2];
+}
+
+// ---- 2-D transform of an N x N tile with transposition -------------------------------------------------------
+// entry: v[m] = tile[a = u + T*m][c = p]      (c is the contiguous axis of the source)
+// exit : v[m] = TILE[a' = p][c' = u + T*m]    (to be stored as out[c'][a'], a' contiguous)
+template <int N, int SGN, typename T, class Ctx>
+BFSM_HD void fft_tile(cx<T>* v, cx<T>* lds, int p, int u, const cx<T>* __restrict__ tw, Ctx& ctx) {
+    constexpr int E = Wg<N>::E, TT = Wg<N>::T, LS = Wg<N>::LS;
+    fft_line<N, SGN, T>(v, lds, p, u, tw, ctx);  // along a
+    ctx.sync();
+#pragma unroll
+    for (int m = 0; m < E; ++m) lds[(u + TT * m) * LS + p] = v[m];  // row a', column c
+    ctx.sync();
+#pragma unroll
+    for (int m = 0; m < E; ++m) v[m] = lds[p * LS + (u + TT * m)];  // lane = a', own c = u + T*m
+    fft_line<N, SGN, T>(v, lds, p, u, tw, ctx);  // along c
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Kernel parameter blocks (plain pointers and sizes; filled by the host pipeline)
+// ------------------------------------------------------------------------------------------------------------
+template <typename T>
+struct TileFwdRealParams {   // F1a: real f -> 2-D forward transform of every x-plane
+    const double* f;         // [x][y][z] real (always double at the API boundary)
+    cx<T>* out;              // [x][lz][ly]
+    const cx<T>* tw;
+};
+
+template <typename T>
+struct LineParams {          // generic x-axis pass on an array [x][N*N]
+    const cx<T>* in;
+    cx<T>* out;
+    const cx<T>* tw;
+};
+
+template <typename T>
+struct GainInvParams {       // KA
+    const cx<T>* fhat;       // [lx][lz][ly]
+    cx<T>* a1;               // [slot][lx][y][z]
+    cx<T>* a2;
+    const cx<T>* phx;        // [B][N] phase tables, exp(i*theta) factors; phx carries the 1/G scale
+    const cx<T>* phy;
+    const cx<T>* phz;
+    const cx<T>* tw;
+    long long dir0;          // global index of the chunk's first direction (b = r*M_sph + s)
+    int n_dir;               // directions in this chunk
+    int per_group;           // directions handled by one workgroup (blockIdx.y)
+};
+
+template <typename T>
+struct GainLineParams {      // KB
+    cx<T>* a1;               // in: A1', out: P' (in place)
+    const cx<T>* a2;
+    const cx<T>* tw;
+};
+
+template <typename T>
+struct GainFwdParams {       // KC
+    const cx<T>* p;          // [slot][x][y][z]
+    cx<T>* slab;             // [chunk_slab0 + group][lx][lz][ly]
+    const T* dirw;           // [B] scalar weight of direction b: (1/G) w_r w_s rho_r^(gamma+2)
+    const cx<T>* tw;
+    long long dir0;
+    int n_dir;
+    int per_group;
+    int slab0;               // first slab index of this chunk
+};
+
+template <typename T>
+struct ReduceParams {        // Q_hat[l] = sum_chunks beta1[r(chunk)][|l|^2] * sum_groups slab
+    const cx<T>* slab;
+    cx<T>* qhat;             // [lx][lz][ly]
+    const T* beta1;          // [M_gl][n2max+1]: 4 pi b_gamma sincc(pi rho_r sqrt(n2) / (2L))
+    const int* chunk_r;      // [n_chunks]
+    int n_chunks;
+    int groups;              // slabs per chunk
+    int n2stride;            // n2max + 1
+};
+
+template <typename T>
+struct TailInvParams {       // tail step 1: plane inverse transforms of Q_hat and beta2 * f_hat
+    const cx<T>* qhat;
+    const cx<T>* fhat;
+    const T* beta2;          // [n2max+1], includes the 1/G scale
+    cx<T>* tg;               // [lx][y][z]
+    cx<T>* tl;
+    const cx<T>* tw;
+};
+
+template <typename T>
+struct TailLineParams {      // tail step 2: x inverse of both, Q = Re(gain) - Re(loss) * f
+    const cx<T>* tg;
+    const cx<T>* tl;
+    const double* f;
+    double* Q;
+    const cx<T>* tw;
+};
+
+BFSM_HD int mode_of(int i, int n) { return i < n / 2 ? i : i - n; }
+
+// ------------------------------------------------------------------------------------------------------------
+// Kernel bodies.  Workgroup = Wg<N>::THREADS threads, tid = u*N + p.
+// ------------------------------------------------------------------------------------------------------------
+
+// F1a.  grid.x = N (x planes).  Replaces copy_to_complex (BoltzmannCUDAKernels.cu:4-16) + the (y,z) part of
+// cufftExecZ2Z(plan3d, f, f_hat, FORWARD) (CUDABoltzmannOperator.cu:137-140).
+template <int N, typename T, class Ctx>
+BFSM_HD void body_tile_fwd_real(const TileFwdRealParams<T>& prm, Ctx& ctx) {
+    constexpr int E = Wg<N>::E, TT = Wg<N>::T;
+    const int tid = ctx.tid(), p = tid % N, u = ctx.uniform(tid / N, N);
+    const int x = ctx.bx();
+    cx<T>* lds = ctx.template lds<cx<T>>();
+    cx<T> v[E];
+    const double* src = prm.f + (size_t)x * N * N;
+#pragma unroll
+    for (int m = 0; m < E; ++m) v[m] = {(T)src[(u + TT * m) * N + p], (T)0};
+    fft_tile<N, -1, T>(v, lds, p, u, prm.tw, ctx);
+    cx<T>* dst = prm.out + (size_t)x * N * N;
+#pragma unroll
+    for (int m = 0; m < E; ++m) dst[(u + TT * m) * N + p] = v[m];
+}
+
+// Generic complex 2-D tile pass (bfsm_fft3d only).  grid = (N planes, batch); in place is allowed because the
+// workgroup holds its whole plane in registers before it stores.  in [a][c] -> out [c'][a'].
+template <int N, int SGN, typename T, class Ctx>
+BFSM_HD void body_tile_c2c(const LineParams<T>& prm, Ctx& ctx) {
+    constexpr int E = Wg<N>::E, TT = Wg<N>::T;
+    const int tid = ctx.tid(), p = tid % N, u = ctx.uniform(tid / N, N);
+    const size_t base = ((size_t)ctx.by() * N + ctx.bx()) * N * N;
+    cx<T>* lds = ctx.template lds<cx<T>>();
+    cx<T> v[E];
+#pragma unroll
+    for (int m = 0; m < E; ++m) v[m] = prm.in[base + (u + TT * m) * N + p];
+    fft_tile<N, SGN, T>(v, lds, p, u, prm.tw, ctx);
+    ctx.sync();  // in place: every thread of the plane has loaded before anyone stores (loads precede the syncs above)
+#pragma unroll
+    for (int m = 0; m < E; ++m) prm.out[base + (u + TT * m) * N + p] = v[m];
+}
+
+// Generic x-axis pass.  grid.x = N (rows of N contiguous elements inside a plane), grid.y = batch.
+template <int N, int SGN, typename T, class Ctx>
+BFSM_HD void body_line(const LineParams<T>& prm, Ctx& ctx) {
+    constexpr int E = Wg<N>::E, TT = Wg<N>::T;
+    const int tid = ctx.tid(), p = tid % N, u = ctx.uniform(tid / N, N);
+    const size_t base = (size_t)ctx.by() * N * N * N + (size_t)ctx.bx() * N + p;
+    cx<T>* lds = ctx.template lds<cx<T>>();
+    cx<T> v[E];
+#pragma unroll
+    for (int m = 0; m < E; ++m) v[m] = prm.in[base + (size_t)(u + TT * m) * N * N];
+    fft_line<N, SGN, T>(v, lds, p, u, prm.tw, ctx);
+#pragma unroll
+    for (int m = 0; m < E; ++m) prm.out[base + (size_t)(u + TT * m) * N * N] = v[m];
+}
+
+// KA.  grid = (N planes lx, groups).  For each direction of the group and both signs: phase multiply
+// (compute_alpha_times_f_hat, BoltzmannCUDAKernels.cu:21-59, with the sincos hoisted into separable tables)
+// fused with the (lz,ly) -> (y,z) part of the two batched inverse transforms (CUDABoltzmannOperator.cu:156-164).
+template <int N, typename T, class Ctx>
+BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
+    constexpr int E = Wg<N>::E, TT = Wg<N>::T;
+    const int tid = ctx.tid(), p = tid % N, u = ctx.uniform(tid / N, N);
+    const int lxi = ctx.bx();
+    cx<T>* lds = ctx.template lds<cx<T>>();
+    cx<T> fh[E];
+    const cx<T>* src = prm.fhat + (size_t)lxi * N * N;
+#pragma unroll
+    for (int m = 0; m < E; ++m) fh[m] = src[(u + TT * m) * N + p];  // [lz = u + T m][ly = p]
+    const int d_begin = ctx.by() * prm.per_group;
+    int d_end = d_begin + prm.per_group;
+    if (d_end > prm.n_dir) d_end = prm.n_dir;
+    for (int d = d_begin; d < d_end; ++d) {
+        const size_t b = (size_t)(prm.dir0 + d);
+        // phase of this thread's points: e^{i theta} / G = phx[lx] * phy[ly = p] * phz[lz = u + T m]; the phz
+        // factors are wave-uniform (scalar loads), so they are re-read per sign instead of held in registers
+        const cx<T> c0 = cmul(prm.phx[b * N + lxi], prm.phy[b * N + p]);
+        const cx<T>* __restrict__ pz = prm.phz + b * N + u;
+        const size_t obase = ((size_t)d * N + lxi) * N * N;
+        cx<T> v[E];
+#pragma unroll
+        for (int m = 0; m < E; ++m) v[m] = cmul(fh[m], cmul(c0, pz[TT * m]));    // alpha1 * f_hat / G
+        fft_tile<N, +1, T>(v, lds, p, u, prm.tw, ctx);
+#pragma unroll
+        for (int m = 0; m < E; ++m) prm.a1[obase + (size_t)(u + TT * m) * N + p] = v[m];  // [y][z = p]
+#pragma unroll
+        for (int m = 0; m < E; ++m) v[m] = cmulc(fh[m], cmul(c0, pz[TT * m]));   // conj(alpha1) * f_hat / G
+        fft_tile<N, +1, T>(v, lds, p, u, prm.tw, ctx);
+#pragma unroll
+        for (int m = 0; m < E; ++m) prm.a2[obase + (size_t)(u + TT * m) * N + p] = v[m];
+    }
+}
+
+// KB.  grid = (N rows y, directions of the chunk).  x-part of the two inverse transforms, hadamard_product
+// (BoltzmannCUDAKernels.cu:62-74) in registers, x-part of the forward transform (CUDABoltzmannOperator.cu:175-178).
+template <int N, typename T, class Ctx>
+BFSM_HD void body_gain_line(const GainLineParams<T>& prm, Ctx& ctx) {
+    constexpr int E = Wg<N>::E, TT = Wg<N>::T;
+    const int tid = ctx.tid(), p = tid % N, u = ctx.uniform(tid / N, N);
+    const size_t base = (size_t)ctx.by() * N * N * N + (size_t)ctx.bx() * N + p;
+    cx<T>* lds = ctx.template lds<cx<T>>();
+    cx<T> a[E], b[E];
+#pragma unroll
+    for (int m = 0; m < E; ++m) a[m] = prm.a1[base + (size_t)(u + TT * m) * N * N];
+#pragma unroll
+    for (int m = 0; m < E; ++m) b[m] = prm.a2[base + (size_t)(u + TT * m) * N * N];
+    fft_line<N, +1, T>(a, lds, p, u, prm.tw, ctx);
+    fft_line<N, +1, T>(b, lds, p, u, prm.tw, ctx);
+#pragma unroll
+    for (int m = 0; m < E; ++m) a[m] = cmul(a[m], b[m]);
+    fft_line<N, -1, T>(a, lds, p, u, prm.tw, ctx);
+#pragma unroll
+    for (int m = 0; m < E; ++m) prm.a1[base + (size_t)(u + TT * m) * N * N] = a[m];
+}
+
+// KC.  grid = (N planes x, groups).  (y,z) part of the forward transform + the direction sum of
+// atomic_tensor_contraction (BoltzmannCUDAKernels.cu:79-123) kept in registers: no atomics, one slab store.
+// beta1 depends on the radial node only, so it is applied once per chunk by body_reduce.
+template <int N, typename T, class Ctx>
+BFSM_HD void body_gain_fwd(const GainFwdParams<T>& prm, Ctx& ctx) {
+    constexpr int E = Wg<N>::E, TT = Wg<N>::T;
+    const int tid = ctx.tid(), p = tid % N, u = ctx.uniform(tid / N, N);
+    const int x = ctx.bx();
+    cx<T>* lds = ctx.template lds<cx<T>>();
+    cx<T> acc[E];
+#pragma unroll
+    for (int m = 0; m < E; ++m) acc[m] = {(T)0, (T)0};
+    const int d_begin = ctx.by() * prm.per_group;
+    int d_end = d_begin + prm.per_group;
+    if (d_end > prm.n_dir) d_end = prm.n_dir;
+    for (int d = d_begin; d < d_end; ++d) {
+        const cx<T>* src = prm.p + ((size_t)d * N + x) * N * N;
+        cx<T> v[E];
+#pragma unroll
+        for (int m = 0; m < E; ++m) v[m] = src[(u + TT * m) * N + p];  // [y = u + T m][z = p]
+        fft_tile<N, -1, T>(v, lds, p, u, prm.tw, ctx);
+        const T w = prm.dirw[prm.dir0 + d];
+#pragma unroll
+        for (int m = 0; m < E; ++m) {
+            acc[m].x += w * v[m].x;
+            acc[m].y += w * v[m].y;
+        }
+    }
+    cx<T>* dst = prm.slab + ((size_t)(prm.slab0 + ctx.by()) * N + x) * N * N;
+#pragma unroll
+    for (int m = 0; m < E; ++m) dst[(u + TT * m) * N + p] = acc[m];   // [lz = u + T m][ly = p]
+}
+
+// Reduce.  One thread per spectral point, grid.x * blockDim = G.  Applies beta1 (the per-point part of
+// BoltzmannCUDAKernels.cu:113-114) and sums the write-once slabs in a fixed order (deterministic).
+template <int N, typename T, class Ctx>
+BFSM_HD void body_reduce(const ReduceParams<T>& prm, Ctx& ctx) {
+    const size_t G = (size_t)N * N * N;
+    const size_t idx = (size_t)ctx.bx() * ctx.nthreads() + ctx.tid();
+    if (idx >= G) return;
+    const int ly = (int)(idx % N), lz = (int)((idx / N) % N), lx = (int)(idx / ((size_t)N * N));
+    const int mx = mode_of(lx, N), my = mode_of(ly, N), mz = mode_of(lz, N);
+    const int n2 = mx * mx + my * my + mz * mz;
+    cx<T> q = {(T)0, (T)0};
+    for (int c = 0; c < prm.n_chunks; ++c) {
+        cx<T> s = {(T)0, (T)0};
+        for (int g = 0; g < prm.groups; ++g) {
+            const cx<T> t = prm.slab[(size_t)(c * prm.groups + g) * G + idx];
+            s.x += t.x;
+            s.y += t.y;
+        }
+        const T b1 = prm.beta1[(size_t)prm.chunk_r[c] * prm.n2stride + n2];
+        q.x += b1 * s.x;
+        q.y += b1 * s.y;
+    }
+    prm.qhat[idx] = q;
+}
+
+// Tail 1.  grid = (N planes lx, 2).  y==0: Q_hat plane; y==1: beta2 * f_hat / G
+// (compute_beta2_times_f_hat, BoltzmannCUDAKernels.cu:126-159, with beta2 tabulated by |l|^2), then the
+// (lz,ly) -> (y,z) part of the two single inverse transforms (CUDABoltzmannOperator.cu:203-212).
+template <int N, typename T, class Ctx>
+BFSM_HD void body_tail_inv(const TailInvParams<T>& prm, Ctx& ctx) {
+    constexpr int E = Wg<N>::E, TT = Wg<N>::T;
+    const int tid = ctx.tid(), p = tid % N, u = ctx.uniform(tid / N, N);
+    const int lxi = ctx.bx();
+    const bool loss = ctx.by() != 0;
+    cx<T>* lds = ctx.template lds<cx<T>>();
+    cx<T> v[E];
+    const size_t pbase = (size_t)lxi * N * N;
+    if (!loss) {
+#pragma unroll
+        for (int m = 0; m < E; ++m) v[m] = prm.qhat[pbase + (u + TT * m) * N + p];
+    } else {
+        const int mx = mode_of(lxi, N), my = mode_of(p, N);
+#pragma unroll
+        for (int m = 0; m < E; ++m) {
+            const int mz = mode_of(u + TT * m, N);
+            const T b2 = prm.beta2[mx * mx + my * my + mz * mz];
+            const cx<T> t = prm.fhat[pbase + (u + TT * m) * N + p];
+            v[m] = {b2 * t.x, b2 * t.y};
+        }
+    }
+    fft_tile<N, +1, T>(v, lds, p, u, prm.tw, ctx);
+    cx<T>* dst = (loss ? prm.tl : prm.tg) + pbase;
+#pragma unroll
+    for (int m = 0; m < E; ++m) dst[(u + TT * m) * N + p] = v[m];
+}
+
+// Tail 2.  grid.x = N rows y.  x-part of both inverse transforms + compute_Q_total
+// (BoltzmannCUDAKernels.cu:162-177): Q = Re(Q_gain) - Re(beta2_times_f * f), f real.
+template <int N, typename T, class Ctx>
+BFSM_HD void body_tail_line(const TailLineParams<T>& prm, Ctx& ctx) {
+    constexpr int E = Wg<N>::E, TT = Wg<N>::T;
+    const int tid = ctx.tid(), p = tid % N, u = ctx.uniform(tid / N, N);
+    const size_t base = (size_t)ctx.bx() * N + p;
+    cx<T>* lds = ctx.template lds<cx<T>>();
+    cx<T> g[E], l[E];
+#pragma unroll
+    for (int m = 0; m < E; ++m) g[m] = prm.tg[base + (size_t)(u + TT * m) * N * N];
+#pragma unroll
+    for (int m = 0; m < E; ++m) l[m] = prm.tl[base + (size_t)(u + TT * m) * N * N];
+    fft_line<N, +1, T>(g, lds, p, u, prm.tw, ctx);
+    fft_line<N, +1, T>(l, lds, p, u, prm.tw, ctx);
+#pragma unroll
+    for (int m = 0; m < E; ++m) {
+        const size_t i = base + (size_t)(u + TT * m) * N * N;
+        prm.Q[i] = (double)g[m].x - (double)l[m].x * prm.f[i];
+    }
+}
+
+}  // namespace bfsm

@@ -1,0 +1,308 @@
+// bfsm_hip.hip -- gfx950 kernels (instantiations of the bodies in bfsm_core.hpp) and the C-ABI of include/bfsm.h.
+// Built with: hipcc --offload-arch=gfx950 -O3 -fPIC -shared  (see ../Makefile).  No rocFFT / hipFFT / MFMA.
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "bfsm_pipeline.hpp"
+
+namespace bfsm {
+
+// ---- device execution context ---------------------------------------------------------------------------------
+struct DevCtx {
+    unsigned char* smem;
+    __device__ __forceinline__ int tid() const { return (int)threadIdx.x; }
+    __device__ __forceinline__ int nthreads() const { return (int)blockDim.x; }
+    __device__ __forceinline__ int bx() const { return (int)blockIdx.x; }
+    __device__ __forceinline__ int by() const { return (int)blockIdx.y; }
+    __device__ __forceinline__ void sync() const { __syncthreads(); }
+    // value known to be equal across a wave when a row of n lanes covers whole waves: make it an SGPR so the
+    // twiddle / phase-table loads that depend on it become scalar loads
+    __device__ __forceinline__ int uniform(int v, int n) const {
+        return (n % 64 == 0) ? __builtin_amdgcn_readfirstlane(v) : v;
+    }
+    template <class U>
+    __device__ __forceinline__ U* lds() const { return reinterpret_cast<U*>(smem); }
+};
+
+template <K kind, int N>
+constexpr int kernel_threads() { return kind == K::Reduce ? 256 : Wg<N>::THREADS; }
+
+template <K kind, int N, typename T, class P>
+__global__ void __launch_bounds__((kernel_threads<kind, N>())) bfsm_kernel(const P prm) {
+    extern __shared__ __align__(16) unsigned char bfsm_smem[];
+    DevCtx ctx{bfsm_smem};
+    if constexpr (kind == K::TileFwdReal) body_tile_fwd_real<N, T>(prm, ctx);
+    else if constexpr (kind == K::LineFwd) body_line<N, -1, T>(prm, ctx);
+    else if constexpr (kind == K::LineInv) body_line<N, +1, T>(prm, ctx);
+    else if constexpr (kind == K::TileFwd) body_tile_c2c<N, -1, T>(prm, ctx);
+    else if constexpr (kind == K::TileInv) body_tile_c2c<N, +1, T>(prm, ctx);
+    else if constexpr (kind == K::GainInv) body_gain_inv<N, T>(prm, ctx);
+    else if constexpr (kind == K::GainLine) body_gain_line<N, T>(prm, ctx);
+    else if constexpr (kind == K::GainFwd) body_gain_fwd<N, T>(prm, ctx);
+    else if constexpr (kind == K::Reduce) body_reduce<N, T>(prm, ctx);
+    else if constexpr (kind == K::TailInv) body_tail_inv<N, T>(prm, ctx);
+    else if constexpr (kind == K::TailLine) body_tail_line<N, T>(prm, ctx);
+}
+
+// ---- HIP backend -----------------------------------------------------------------------------------------------
+struct HipBackend {
+    hipStream_t stream = nullptr;
+    bool profile = false;
+    hipError_t first_error = hipSuccess;
+    const char* first_error_where = "";
+    int first_error_line = 0;
+
+    struct Rec { int kind; double bytes; hipEvent_t e0, e1; };
+    std::vector<Rec> recs;        // launches of the current profiled evaluation
+    std::vector<hipEvent_t> pool; // reusable events
+    size_t pool_next = 0;
+    int pend_kind = -1;
+    double pend_bytes = 0;
+
+    void note(hipError_t e, const char* where, int line) {
+        if (e != hipSuccess && first_error == hipSuccess) { first_error = e; first_error_where = where; first_error_line = line; }
+    }
+#define BFSM_NOTE(call) note((call), #call, __LINE__)
+
+    void* alloc(size_t bytes) {
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, bytes);
+        note(e, "hipMalloc", __LINE__);
+        return e == hipSuccess ? p : nullptr;
+    }
+    void release(void* p) { BFSM_NOTE(hipFree(p)); }
+    void upload(void* dst, const void* src, size_t bytes) { BFSM_NOTE(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); }
+
+    hipEvent_t next_event() {
+        if (pool_next == pool.size()) {
+            hipEvent_t e;
+            BFSM_NOTE(hipEventCreate(&e));
+            pool.push_back(e);
+        }
+        return pool[pool_next++];
+    }
+    void begin_eval() { recs.clear(); pool_next = 0; }
+    void mark(int kind, double bytes) { pend_kind = kind; pend_bytes = bytes; }
+
+    template <K kind, int N, typename T, class P>
+    void launch_n(int gx, int gy, const P& prm) {
+        constexpr int threads = kernel_threads<kind, N>();
+        constexpr size_t lds = kind == K::Reduce ? 0 : (size_t)Wg<N>::LDS_ELEMS * sizeof(cx<T>);
+        auto fn = bfsm_kernel<kind, N, T, P>;
+        static std::once_flag once;   // one per instantiation
+        std::call_once(once, [&] {
+            if (lds > 48 * 1024)
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        });
+        Rec rec{pend_kind, pend_bytes, nullptr, nullptr};
+        const bool timed = profile && pend_kind >= 0;
+        if (timed) { rec.e0 = next_event(); rec.e1 = next_event(); BFSM_NOTE(hipEventRecord(rec.e0, stream)); }
+        hipLaunchKernelGGL(fn, dim3((unsigned)gx, (unsigned)gy, 1), dim3(threads, 1, 1), lds, stream, prm);
+        BFSM_NOTE(hipGetLastError());
+        if (timed) { BFSM_NOTE(hipEventRecord(rec.e1, stream)); recs.push_back(rec); }
+        pend_kind = -1;
+    }
+
+    template <K kind, typename T, class P>
+    void launch(int gx, int gy, const P& prm, int N) {
+        if (gx <= 0 || gy <= 0) return;
+        switch (N) {
+            case 16: launch_n<kind, 16, T>(gx, gy, prm); break;
+            case 32: launch_n<kind, 32, T>(gx, gy, prm); break;
+            case 64: launch_n<kind, 64, T>(gx, gy, prm); break;
+            case 128:
+                if constexpr (sizeof(T) == 4) launch_n<kind, 128, T>(gx, gy, prm);
+                break;
+            default: break;
+        }
+    }
+
+    void destroy_events() {
+        for (hipEvent_t e : pool) (void)hipEventDestroy(e);
+        pool.clear();
+    }
+};
+
+}  // namespace bfsm
+
+// ---- the handle ------------------------------------------------------------------------------------------------
+struct bfsm_plan {
+    bfsm_desc desc{};
+    bfsm::HipBackend be;
+    bfsm::Pipeline<double, bfsm::HipBackend>* p64 = nullptr;
+    bfsm::Pipeline<float, bfsm::HipBackend>* p32 = nullptr;
+    bfsm::PlanInfo info;
+    std::string err;
+    bfsm_counters counters{};
+    bool full_shard = true;
+};
+
+static thread_local std::string g_create_error;
+
+static int fail(bfsm_plan* h, int code, const std::string& msg) {
+    if (h) h->err = msg; else g_create_error = msg;
+    return code;
+}
+
+static int check_hip(bfsm_plan* h, const char* where) {
+    if (h->be.first_error == hipSuccess) return BFSM_OK;
+    std::string m = std::string("HIP error: ") + hipGetErrorString(h->be.first_error) + " in " + h->be.first_error_where +
+                    " at bfsm_hip.hip:" + std::to_string(h->be.first_error_line) + " (during " + where + ")";
+    h->be.first_error = hipSuccess;
+    return fail(h, BFSM_ERR_HIP, m);
+}
+
+extern "C" {
+
+const char* bfsm_backend_name(void) { return "HIP"; }
+int bfsm_version(void) { return BFSM_VERSION; }
+
+const char* bfsm_last_error(bfsm_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int bfsm_create(const bfsm_desc* desc, bfsm_handle* out) {
+    if (!desc || !out) return fail(nullptr, BFSM_ERR_INVALID, "null argument");
+    *out = nullptr;
+    std::string err;
+    int rc = bfsm::validate_desc(*desc, err);
+    if (rc != BFSM_OK) return fail(nullptr, rc, err);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, BFSM_ERR_HIP, std::string("no HIP device available: ") + hipGetErrorString(e));
+    if (desc->device < 0 || desc->device >= ndev) return fail(nullptr, BFSM_ERR_INVALID, "device ordinal out of range");
+    e = hipSetDevice(desc->device);
+    if (e != hipSuccess) return fail(nullptr, BFSM_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    bfsm_plan* h = new (std::nothrow) bfsm_plan();
+    if (!h) return fail(nullptr, BFSM_ERR_NOMEM, "out of host memory");
+    h->desc = *desc;
+    h->be.profile = (desc->flags & BFSM_FLAG_PROFILE) != 0;
+    if (desc->precision == BFSM_F64) {
+        h->p64 = new bfsm::Pipeline<double, bfsm::HipBackend>();
+        rc = h->p64->init(*desc, &h->be, err);
+        h->info = h->p64->plan;
+    } else {
+        h->p32 = new bfsm::Pipeline<float, bfsm::HipBackend>();
+        rc = h->p32->init(*desc, &h->be, err);
+        h->info = h->p32->plan;
+    }
+    // the descriptor's host arrays are not referenced after create
+    h->desc.gl_nodes = h->desc.gl_wts = h->desc.sph_wts = h->desc.sx = h->desc.sy = h->desc.sz = nullptr;
+    h->full_shard = h->info.dir_begin == 0 && h->info.dir_end == (long long)desc->n_gl * desc->n_sph;
+    if (rc == BFSM_OK) rc = check_hip(h, "bfsm_create");
+    else if (h->be.first_error != hipSuccess) { (void)check_hip(h, "bfsm_create"); err = h->err; }
+    if (rc != BFSM_OK) {
+        g_create_error = h->err.empty() ? err : h->err;
+        bfsm_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return BFSM_OK;
+}
+
+static int enter(bfsm_plan* h, void* stream) {
+    if (!h) return BFSM_ERR_INVALID;
+    hipError_t e = hipSetDevice(h->desc.device);
+    if (e != hipSuccess) return fail(h, BFSM_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    h->be.stream = (hipStream_t)stream;
+    return BFSM_OK;
+}
+
+int bfsm_gain_partial(bfsm_handle h, const double* f_dev, void* stream) {
+    int rc = enter(h, stream);
+    if (rc) return rc;
+    if (!f_dev) return fail(h, BFSM_ERR_INVALID, "null f");
+    h->be.begin_eval();
+    if (h->p64) h->p64->gain_partial(f_dev); else h->p32->gain_partial(f_dev);
+    return check_hip(h, "bfsm_gain_partial");
+}
+
+int bfsm_finish(bfsm_handle h, double* Q_dev, const double* f_dev, void* stream) {
+    int rc = enter(h, stream);
+    if (rc) return rc;
+    if (!f_dev || !Q_dev) return fail(h, BFSM_ERR_INVALID, "null f or Q");
+    if (h->p64) h->p64->finish(Q_dev, f_dev); else h->p32->finish(Q_dev, f_dev);
+    return check_hip(h, "bfsm_finish");
+}
+
+int bfsm_collide_async(bfsm_handle h, double* Q_dev, const double* f_dev, void* stream) {
+    if (!h) return BFSM_ERR_INVALID;
+    if (!h->full_shard)
+        return fail(h, BFSM_ERR_INVALID, "bfsm_collide needs a handle that owns all directions; use gain_partial + reduce + finish");
+    int rc = bfsm_gain_partial(h, f_dev, stream);
+    if (rc) return rc;
+    return bfsm_finish(h, Q_dev, f_dev, stream);
+}
+
+int bfsm_collide(bfsm_handle h, double* Q_dev, const double* f_dev) {
+    int rc = bfsm_collide_async(h, Q_dev, f_dev, nullptr);
+    if (rc) return rc;
+    return bfsm_synchronize(h);
+}
+
+int bfsm_synchronize(bfsm_handle h) {
+    if (!h) return BFSM_ERR_INVALID;
+    hipError_t e = hipSetDevice(h->desc.device);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->be.stream);
+    if (e != hipSuccess) return fail(h, BFSM_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+    return BFSM_OK;
+}
+
+void* bfsm_qhat_buffer(bfsm_handle h, size_t* n_elems, int* precision) {
+    if (!h) return nullptr;
+    if (n_elems) *n_elems = 2 * h->info.G();
+    if (precision) *precision = h->info.precision;
+    return h->p64 ? (void*)h->p64->qhat : (void*)h->p32->qhat;
+}
+
+int bfsm_fft3d(bfsm_handle h, void* data_dev, int batch, int sign) {
+    int rc = enter(h, nullptr);
+    if (rc) return rc;
+    if (!data_dev || batch < 1 || (sign != 1 && sign != -1)) return fail(h, BFSM_ERR_INVALID, "bad fft3d argument");
+    if (h->p64) h->p64->fft3d((bfsm::cx<double>*)data_dev, batch, sign);
+    else h->p32->fft3d((bfsm::cx<float>*)data_dev, batch, sign);
+    rc = check_hip(h, "bfsm_fft3d");
+    if (rc) return rc;
+    return bfsm_synchronize(h);
+}
+
+int bfsm_get_counters(bfsm_handle h, bfsm_counters* out) {
+    if (!h || !out) return BFSM_ERR_INVALID;
+    bfsm_counters c{};
+    c.alg_bytes_per_eval = bfsm::alg_bytes_per_eval(h->info);
+    c.n_chunks = (int)h->info.chunks.size();
+    c.chunk_dirs = h->info.largest_chunk;
+    c.n_dirs = h->info.n_dirs();
+    if (h->be.profile && !h->be.recs.empty()) {
+        hipError_t e = hipStreamSynchronize(h->be.stream);
+        if (e != hipSuccess) return fail(h, BFSM_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+        for (const auto& r : h->be.recs) {
+            float ms = 0.f;
+            e = hipEventElapsedTime(&ms, r.e0, r.e1);
+            if (e != hipSuccess) return fail(h, BFSM_ERR_HIP, std::string("hipEventElapsedTime: ") + hipGetErrorString(e));
+            if (r.kind >= 0 && r.kind < BFSM_K_COUNT) {
+                c.kernel_ms[r.kind] += ms;
+                c.kernel_alg_bytes[r.kind] += r.bytes;
+                c.kernel_launches[r.kind] += 1;
+            }
+        }
+    }
+    *out = c;
+    return BFSM_OK;
+}
+
+int bfsm_destroy(bfsm_handle h) {
+    if (!h) return BFSM_OK;
+    (void)hipSetDevice(h->desc.device);
+    (void)hipDeviceSynchronize();
+    if (h->p64) { h->p64->destroy(); delete h->p64; }
+    if (h->p32) { h->p32->destroy(); delete h->p32; }
+    h->be.destroy_events();
+    delete h;
+    return BFSM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,309 @@
+// bfsm_pipeline.hpp -- host-side plan (tables, direction chunks) and the launch sequence of one collision
+// evaluation.  Pure C++17, no HIP types: the sequence is a template over a `Backend` that owns memory and
+// launches the kernel bodies of bfsm_core.hpp.  bfsm_hip.hip provides the HIP backend (the product);
+// tests/emu provides a host lock-step backend so the same plan + sequence is unit-tested without a GPU.
+//
+// What is computed ("the algorithm in one block"; Collisions/FFTWBoltzmannOperator.cpp:147-334):
+//   f_hat = FFT(f)
+//   for every direction b=(r,s) of this shard:   A1 = IFFT(e^{+i theta} f_hat / G), A2 = IFFT(e^{-i theta} f_hat / G)
+//                                                 P_hat = FFT(A1 * A2)
+//                                                 Q_hat += (1/G) w_r w_s rho_r^(gamma+2) * beta1(r,|l|) * P_hat
+//   Q = Re IFFT(Q_hat) - Re(IFFT(beta2 f_hat / G)) * f
+#pragma once
+#include <cmath>
+#include <cfloat>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/bfsm.h"
+#include "bfsm_core.hpp"
+
+namespace bfsm {
+
+struct Chunk {
+    int r;            // radial node shared by all directions of the chunk (beta1 depends on r only)
+    long long dir0;   // first direction, LOCAL index inside the shard (tables are shard-local)
+    int n;            // directions in the chunk
+    int per_group;    // directions per accumulating workgroup
+    int slab0;        // first slab of the chunk
+};
+
+struct PlanInfo {
+    int N = 0;
+    int precision = 64;
+    int n_gl = 0, n_sph = 0;
+    long long dir_begin = 0, dir_end = 0;  // global direction range of the shard
+    int max_chunk = 64;
+    int groups = 8;                        // accumulating workgroups per x-plane (slabs per chunk)
+    int n2stride = 0;                      // 3*(N/2)^2 + 1
+    std::vector<Chunk> chunks;
+    int largest_chunk = 0;
+    size_t G() const { return (size_t)N * N * N; }
+    long long n_dirs() const { return dir_end - dir_begin; }
+};
+
+// sincc(x) = sin(x+eps)/(x+eps)  (Collisions/FFTWBoltzmannOperator.hpp:17-21, BoltzmannCUDAKernels.hpp:17-29)
+inline double sincc_ref(double x) {
+    const double eps = DBL_EPSILON;
+    return std::sin(x + eps) / (x + eps);
+}
+
+inline int validate_desc(const bfsm_desc& d, std::string& err) {
+    if (d.nvx != d.nvy || d.nvx != d.nvz) { err = "nvx, nvy, nvz must be equal in this build"; return BFSM_ERR_UNSUPPORTED; }
+    const int N = d.nvx;
+    if (N != 16 && N != 32 && N != 64 && N != 128) { err = "grid size must be one of 16, 32, 64, 128"; return BFSM_ERR_UNSUPPORTED; }
+    if (d.precision != BFSM_F64 && d.precision != BFSM_F32) { err = "precision must be BFSM_F64 or BFSM_F32"; return BFSM_ERR_INVALID; }
+    if (N == 128 && d.precision == BFSM_F64) { err = "N=128 needs BFSM_F32 (a 128x128 double tile exceeds the 160 KiB LDS)"; return BFSM_ERR_UNSUPPORTED; }
+    if (d.n_gl < 1 || d.n_sph < 1) { err = "n_gl and n_sph must be positive"; return BFSM_ERR_INVALID; }
+    if (!d.gl_nodes || !d.gl_wts || !d.sph_wts || !d.sx || !d.sy || !d.sz) { err = "null quadrature array"; return BFSM_ERR_INVALID; }
+    if (!(d.L > 0)) { err = "L must be positive"; return BFSM_ERR_INVALID; }
+    const long long B = (long long)d.n_gl * d.n_sph;
+    if (!(d.dir_begin == 0 && d.dir_end == 0) && (d.dir_begin < 0 || d.dir_end > B || d.dir_begin > d.dir_end)) {
+        err = "direction shard out of range"; return BFSM_ERR_INVALID;
+    }
+    if (d.max_chunk < 0) { err = "max_chunk must be >= 0"; return BFSM_ERR_INVALID; }
+    return BFSM_OK;
+}
+
+inline PlanInfo make_plan(const bfsm_desc& d) {
+    PlanInfo p;
+    p.N = d.nvx;
+    p.precision = d.precision;
+    p.n_gl = d.n_gl;
+    p.n_sph = d.n_sph;
+    const long long B = (long long)d.n_gl * d.n_sph;
+    if (d.dir_begin == 0 && d.dir_end == 0) { p.dir_begin = 0; p.dir_end = B; }
+    else { p.dir_begin = d.dir_begin; p.dir_end = d.dir_end; }
+    p.max_chunk = d.max_chunk > 0 ? d.max_chunk : 64;
+    p.groups = (512 + p.N - 1) / p.N;           // >= 2 workgroups per CU on 256 CUs
+    if (p.groups > p.max_chunk) p.groups = p.max_chunk;
+    if (p.groups < 1) p.groups = 1;
+    p.n2stride = 3 * (p.N / 2) * (p.N / 2) + 1;
+    int slab = 0;
+    long long b = p.dir_begin;
+    while (b < p.dir_end) {
+        const int r = (int)(b / d.n_sph);
+        long long r_end = (long long)(r + 1) * d.n_sph;
+        if (r_end > p.dir_end) r_end = p.dir_end;
+        const long long len = r_end - b;
+        const long long pieces = (len + p.max_chunk - 1) / p.max_chunk;
+        const long long piece = (len + pieces - 1) / pieces;
+        for (long long o = 0; o < len; o += piece) {
+            Chunk c;
+            c.r = r;
+            c.dir0 = (b + o) - p.dir_begin;
+            c.n = (int)((o + piece <= len) ? piece : (len - o));
+            c.per_group = (c.n + p.groups - 1) / p.groups;
+            c.slab0 = slab;
+            slab += p.groups;
+            if (c.n > p.largest_chunk) p.largest_chunk = c.n;
+            p.chunks.push_back(c);
+        }
+        b = r_end;
+    }
+    return p;
+}
+
+// Host tables, built in double / long double, then narrowed to T.
+template <typename T>
+struct HostTables {
+    std::vector<cx<T>> tw;                 // [N]
+    std::vector<cx<T>> phx, phy, phz;      // [n_dirs][N]
+    std::vector<T> dirw;                   // [n_dirs]
+    std::vector<T> beta1;                  // [n_gl][n2stride]
+    std::vector<T> beta2;                  // [n2stride]
+    std::vector<int> chunk_r;              // [n_chunks]
+};
+
+template <typename T>
+HostTables<T> build_tables(const bfsm_desc& d, const PlanInfo& p) {
+    HostTables<T> t;
+    const int N = p.N;
+    const double pi = 3.14159265358979323846;  // Utilities/constants.hpp:7
+    const long double PI_L = 3.141592653589793238462643383279502884L;
+    const double G = (double)p.G();
+    const double fft_scale = 1.0 / G;          // FFTWBoltzmannOperator.cpp:162
+    t.tw.resize(N);
+    for (int n = 0; n < N; ++n) {
+        const long double a = -2.0L * PI_L * (long double)n / (long double)N;
+        t.tw[n] = {(T)cosl(a), (T)sinl(a)};
+    }
+    const long long nd = p.n_dirs();
+    t.phx.resize((size_t)nd * N);
+    t.phy.resize((size_t)nd * N);
+    t.phz.resize((size_t)nd * N);
+    t.dirw.resize((size_t)nd);
+    for (long long i = 0; i < nd; ++i) {
+        const long long b = p.dir_begin + i;
+        const int r = (int)(b / d.n_sph), s = (int)(b % d.n_sph);
+        // theta(l) = -(pi/(2L)) rho_r (l . sigma_s)   (FFTWBoltzmannOperator.cpp:205-209), separable in lx, ly, lz
+        const long double k = -((long double)pi / (2.0L * (long double)d.L)) * (long double)d.gl_nodes[r];
+        for (int n = 0; n < N; ++n) {
+            const int l = n < N / 2 ? n : n - N;   // FFT-order mode (FFTWBoltzmannOperator.cpp:50-57)
+            const long double ax = k * (long double)l * (long double)d.sx[s];
+            const long double ay = k * (long double)l * (long double)d.sy[s];
+            const long double az = k * (long double)l * (long double)d.sz[s];
+            t.phx[(size_t)i * N + n] = {(T)(fft_scale * (double)cosl(ax)), (T)(fft_scale * (double)sinl(ax))};
+            t.phy[(size_t)i * N + n] = {(T)cosl(ay), (T)sinl(ay)};
+            t.phz[(size_t)i * N + n] = {(T)cosl(az), (T)sinl(az)};
+        }
+        // weight = fft_scale * gl_wts[r] * spherical_wts[s] * pow(gl_nodes[r], gamma + 2)   (cpp:252)
+        t.dirw[(size_t)i] = (T)(fft_scale * d.gl_wts[r] * d.sph_wts[s] * std::pow(d.gl_nodes[r], d.gamma + 2));
+    }
+    t.beta1.resize((size_t)d.n_gl * p.n2stride);
+    t.beta2.assign((size_t)p.n2stride, (T)0);
+    std::vector<double> b2((size_t)p.n2stride, 0.0);
+    for (int n2 = 0; n2 < p.n2stride; ++n2) {
+        const double norm_l = std::sqrt((double)n2);
+        for (int r = 0; r < d.n_gl; ++r) {
+            // beta1 = 4 pi b_gamma sincc(pi rho_r |l| / (2L))   (cpp:261-262)
+            t.beta1[(size_t)r * p.n2stride + n2] = (T)(4 * pi * d.b_gamma * sincc_ref(pi * d.gl_nodes[r] * norm_l / (2 * d.L)));
+            // beta2 += 16 pi^2 b_gamma w_r rho_r^(gamma+2) sincc(pi rho_r |l| / L)   (cpp:290-293)
+            b2[n2] += 16 * pi * pi * d.b_gamma * d.gl_wts[r] * std::pow(d.gl_nodes[r], d.gamma + 2) *
+                      sincc_ref(pi * d.gl_nodes[r] * norm_l / d.L);
+        }
+        t.beta2[n2] = (T)(fft_scale * b2[n2]);   // cpp:295-296 folds fft_scale
+    }
+    t.chunk_r.resize(p.chunks.size());
+    for (size_t c = 0; c < p.chunks.size(); ++c) t.chunk_r[c] = p.chunks[c].r;
+    return t;
+}
+
+// Kernel identifiers the backend dispatches on.
+enum class K { TileFwdReal, LineFwd, LineInv, TileFwd, TileInv, GainInv, GainLine, GainFwd, Reduce, TailInv, TailLine };
+
+// Device-resident state of one handle.  `Backend` supplies:
+//   void* alloc(size_t), void release(void*), void upload(void* dst, const void* src, size_t), void zero(void*, size_t)
+//   template <K kind, typename T, class P> void launch(int grid_x, int grid_y, const P& params, int N)
+//   void mark(int kind, double alg_bytes)              -- accounting tag of the next launch (kind < 0: untracked)
+template <typename T, class Backend>
+struct Pipeline {
+    PlanInfo plan;
+    Backend* be = nullptr;
+    // device buffers
+    cx<T>* fhat = nullptr;
+    cx<T>* tg = nullptr;
+    cx<T>* tl = nullptr;
+    cx<T>* qhat = nullptr;
+    cx<T>* a1 = nullptr;
+    cx<T>* a2 = nullptr;
+    cx<T>* slab = nullptr;
+    cx<T>* tw = nullptr;
+    cx<T>* phx = nullptr;
+    cx<T>* phy = nullptr;
+    cx<T>* phz = nullptr;
+    T* dirw = nullptr;
+    T* beta1 = nullptr;
+    T* beta2 = nullptr;
+    int* chunk_r = nullptr;
+    size_t slab_count = 0;
+
+    template <typename U>
+    bool dev_copy(U*& dst, const std::vector<U>& src) {
+        const size_t bytes = (src.empty() ? 1 : src.size()) * sizeof(U);
+        dst = (U*)be->alloc(bytes);
+        if (!dst) return false;
+        if (!src.empty()) be->upload(dst, src.data(), src.size() * sizeof(U));
+        return true;
+    }
+
+    int init(const bfsm_desc& d, Backend* backend, std::string& err) {
+        be = backend;
+        plan = make_plan(d);
+        HostTables<T> t = build_tables<T>(d, plan);
+        const size_t G = plan.G();
+        const size_t cap = (size_t)(plan.largest_chunk > 0 ? plan.largest_chunk : 1);
+        slab_count = plan.chunks.size() * (size_t)plan.groups;
+        bool ok = true;
+        ok = ok && (fhat = (cx<T>*)be->alloc(G * sizeof(cx<T>)));
+        ok = ok && (tg = (cx<T>*)be->alloc(G * sizeof(cx<T>)));
+        ok = ok && (tl = (cx<T>*)be->alloc(G * sizeof(cx<T>)));
+        ok = ok && (qhat = (cx<T>*)be->alloc(G * sizeof(cx<T>)));
+        ok = ok && (a1 = (cx<T>*)be->alloc(cap * G * sizeof(cx<T>)));
+        ok = ok && (a2 = (cx<T>*)be->alloc(cap * G * sizeof(cx<T>)));
+        ok = ok && (slab = (cx<T>*)be->alloc((slab_count ? slab_count : 1) * G * sizeof(cx<T>)));
+        ok = ok && dev_copy(tw, t.tw) && dev_copy(phx, t.phx) && dev_copy(phy, t.phy) && dev_copy(phz, t.phz);
+        ok = ok && dev_copy(dirw, t.dirw) && dev_copy(beta1, t.beta1) && dev_copy(beta2, t.beta2) && dev_copy(chunk_r, t.chunk_r);
+        if (!ok) { err = "device allocation failed"; return BFSM_ERR_NOMEM; }
+        return BFSM_OK;
+    }
+
+    void destroy() {
+        if (!be) return;
+        void* ptrs[] = {fhat, tg, tl, qhat, a1, a2, slab, tw, phx, phy, phz, dirw, beta1, beta2, chunk_r};
+        for (void* p : ptrs) if (p) be->release(p);
+        fhat = tg = tl = qhat = a1 = a2 = slab = tw = phx = phy = phz = nullptr;
+        dirw = beta1 = beta2 = nullptr;
+        chunk_r = nullptr;
+    }
+
+    double cbytes() const { return (double)sizeof(cx<T>); }
+
+    // f_hat = FFT(f), then the gain term of this shard into qhat (partial Q_gain_hat, spectral layout).
+    void gain_partial(const double* f_dev) {
+        const int N = plan.N;
+        const double Gc = (double)plan.G() * cbytes();
+        {   // F1: f_hat  (CUDABoltzmannOperator.cu:133-140)
+            TileFwdRealParams<T> pa{f_dev, tg, tw};
+            be->mark(BFSM_K_FFT_F, 1.5 * Gc);
+            be->template launch<K::TileFwdReal, T>(N, 1, pa, N);
+            LineParams<T> pb{tg, fhat, tw};
+            be->mark(BFSM_K_FFT_F, 2.0 * Gc);
+            be->template launch<K::LineFwd, T>(N, 1, pb, N);
+        }
+        for (const Chunk& c : plan.chunks) {
+            GainInvParams<T> ka{fhat, a1, a2, phx, phy, phz, tw, c.dir0, c.n, c.per_group};
+            const int ga = (c.n + c.per_group - 1) / c.per_group;
+            be->mark(BFSM_K_GAIN_INV, 2.0 * c.n * Gc);
+            be->template launch<K::GainInv, T>(N, ga, ka, N);
+            GainLineParams<T> kb{a1, a2, tw};
+            be->mark(BFSM_K_GAIN_LINE, 3.0 * c.n * Gc);
+            be->template launch<K::GainLine, T>(N, c.n, kb, N);
+            GainFwdParams<T> kc{a1, slab, dirw, tw, c.dir0, c.n, c.per_group, c.slab0};
+            be->mark(BFSM_K_GAIN_FWD, 1.0 * c.n * Gc);
+            be->template launch<K::GainFwd, T>(N, plan.groups, kc, N);
+        }
+        ReduceParams<T> kr{slab, qhat, beta1, chunk_r, (int)plan.chunks.size(), plan.groups, plan.n2stride};
+        be->mark(BFSM_K_REDUCE, ((double)slab_count + 1.0) * Gc);
+        be->template launch<K::Reduce, T>((int)((plan.G() + 255) / 256), 1, kr, N);
+    }
+
+    // Loss term + final inverse transforms + combine  (CUDABoltzmannOperator.cu:193-216)
+    void finish(double* Q_dev, const double* f_dev) {
+        const int N = plan.N;
+        const double Gc = (double)plan.G() * cbytes();
+        TailInvParams<T> ta{qhat, fhat, beta2, tg, tl, tw};
+        be->mark(BFSM_K_TAIL, 4.0 * Gc);
+        be->template launch<K::TailInv, T>(N, 2, ta, N);
+        TailLineParams<T> tb{tg, tl, f_dev, Q_dev, tw};
+        be->mark(BFSM_K_TAIL, 3.0 * Gc);
+        be->template launch<K::TailLine, T>(N, 1, tb, N);
+    }
+
+    // In-place batched 3-D transform on user data (bfsm_fft3d)
+    int fft3d(cx<T>* data, int batch, int sign) {
+        const int N = plan.N;
+        LineParams<T> p{data, data, tw};
+        if (sign < 0) {
+            be->mark(-1, 0);
+            be->template launch<K::TileFwd, T>(N, batch, p, N);
+            be->mark(-1, 0);
+            be->template launch<K::LineFwd, T>(N, batch, p, N);
+        } else {
+            be->mark(-1, 0);
+            be->template launch<K::LineInv, T>(N, batch, p, N);
+            be->mark(-1, 0);
+            be->template launch<K::TileInv, T>(N, batch, p, N);
+        }
+        return BFSM_OK;
+    }
+};
+
+inline double alg_bytes_per_eval(const PlanInfo& p) {
+    const double c = p.precision == BFSM_F64 ? 16.0 : 8.0;
+    return (6.0 * (double)p.n_dirs() + 9.0) * (double)p.G() * c;
+}
+
+}  // namespace bfsm

@@ -1,0 +1,141 @@
+/*
+ * bfsm.h -- C-ABI of the MI355X-native Fourier-spectral Boltzmann collision operator (libbfsm_hip.so).
+ *
+ * This is the drop-in boundary for ONE path of i3s93/Boltzmann-Fourier-Spectral-Method: a single evaluation of
+ * Q = Q(f,f) behind AbstractCollisionOperator::computeCollision.  Plain pointers and sizes only; no C++ or torch
+ * types.  Each entry point names the reference interface it replaces (file:line relative to the reference root).
+ * The C++ mirror of the reference's operator class (BoltzmannOperator<HIP_Backend>) and the Python ctypes binding
+ * are thin wrappers over exactly these symbols; see INTEGRATION.md.
+ *
+ * Conventions (identical to the reference's CUDA backend, Collisions/CUDABoltzmannOperator.cu:119-220):
+ *   - f and Q are DEVICE pointers to Nvx*Nvy*Nvz contiguous doubles, row-major [i][j][k], k (v_z) contiguous
+ *     (maxwell_bkw_cuda.cu:119-126); they stay owned by the caller, all scratch is owned by the handle.
+ *   - a handle is not re-entrant (shared scratch), like the reference object.
+ *   - functions never throw and never exit: they return BFSM_OK or an error code, and bfsm_last_error() returns a
+ *     human-readable message (the reference prints and std::exit()s, CUDABoltzmannOperator.hpp:20-38; the C++
+ *     wrapper restores that behaviour).
+ */
+#ifndef BFSM_H
+#define BFSM_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BFSM_VERSION 1
+
+enum {
+    BFSM_OK = 0,
+    BFSM_ERR_INVALID = 1,      /* bad argument / descriptor */
+    BFSM_ERR_UNSUPPORTED = 2,  /* grid size / precision combination without a kernel */
+    BFSM_ERR_HIP = 3,          /* a HIP runtime call failed (message has file:line) */
+    BFSM_ERR_NOMEM = 4
+};
+
+enum {
+    BFSM_F64 = 64, /* IEEE double throughout (reference behaviour) */
+    BFSM_F32 = 32  /* single-precision transforms and tables; f and Q stay double at the boundary */
+};
+
+enum {
+    BFSM_FLAG_NONE = 0,
+    BFSM_FLAG_PROFILE = 1 /* record HIP events around every kernel launch (bfsm_get_counters) */
+};
+
+typedef struct bfsm_plan* bfsm_handle;
+
+/*
+ * Operator description == the constructor arguments of BoltzmannOperator<CUDA_Backend>
+ * (Collisions/CUDABoltzmannOperator.hpp:48-54) with the quadrature objects flattened to the arrays the operator
+ * reads from them (getNodes/getWeights, Quadratures/AbstractQuadrature.hpp:17-29; getx/gety/getz/getWeights,
+ * Quadratures/AbstractSphericalQuadratures.hpp:21-42).  All arrays are HOST pointers, copied during create.
+ */
+typedef struct bfsm_desc {
+    int nvx, nvy, nvz;        /* velocity grid; this build has kernels for nvx == nvy == nvz in {16,32,64,128}
+                                 (128 only with BFSM_F32) */
+    int n_gl;                 /* Gauss-Legendre points (radial)          */
+    int n_sph;                /* spherical quadrature points             */
+    const double* gl_nodes;   /* [n_gl]  rho_r on [0,R]                   */
+    const double* gl_wts;     /* [n_gl]                                   */
+    const double* sph_wts;    /* [n_sph]                                  */
+    const double* sx;         /* [n_sph] unit vectors                     */
+    const double* sy;
+    const double* sz;
+    double gamma;             /* kernel exponent (0: Maxwell molecules)   */
+    double b_gamma;           /* kernel constant                          */
+    double L;                 /* half-width of the periodic velocity box  */
+    int precision;            /* BFSM_F64 | BFSM_F32                      */
+    int device;               /* HIP device ordinal                       */
+    long long dir_begin;      /* shard of the flattened quadrature directions b = r*n_sph + s handled by this   */
+    long long dir_end;        /* handle: [dir_begin, dir_end).  0,0 = all directions (single-GPU behaviour).     */
+    int max_chunk;            /* directions resident at once (0 = default 64); bounds scratch, not results       */
+    int flags;                /* BFSM_FLAG_*                              */
+} bfsm_desc;
+
+/* Per-kernel accounting filled when BFSM_FLAG_PROFILE is set (all zero otherwise). */
+enum { BFSM_K_FFT_F = 0, BFSM_K_GAIN_INV = 1, BFSM_K_GAIN_LINE = 2, BFSM_K_GAIN_FWD = 3, BFSM_K_REDUCE = 4,
+       BFSM_K_TAIL = 5, BFSM_K_COUNT = 6 };
+typedef struct bfsm_counters {
+    double alg_bytes_per_eval;            /* (6*B_shard + 9) * G * c, the SURVEY 8(d) model                 */
+    double kernel_ms[BFSM_K_COUNT];       /* summed HIP-event time of the last profiled evaluation         */
+    double kernel_alg_bytes[BFSM_K_COUNT];/* algorithmic bytes moved by those launches                     */
+    int kernel_launches[BFSM_K_COUNT];
+    int n_chunks;
+    int chunk_dirs;                       /* directions in the largest chunk                               */
+    long long n_dirs;                     /* directions of this shard                                      */
+} bfsm_counters;
+
+/* == BoltzmannOperator<CUDA_Backend>::initialize() (CUDABoltzmannOperator.cu:28-115): allocates all device
+ * scratch, uploads quadrature-derived tables, builds twiddles.  Returns a handle through *out. */
+int bfsm_create(const bfsm_desc* desc, bfsm_handle* out);
+
+/* == BoltzmannOperator<CUDA_Backend>::computeCollision(Q, f_in) (CUDABoltzmannOperator.cu:119-220), blocking:
+ * returns after the device work has completed (the reference ends in cudaDeviceSynchronize, cu:218).
+ * Requires a handle that owns ALL directions (dir_begin,dir_end = 0,0 or 0,n_gl*n_sph). */
+int bfsm_collide(bfsm_handle h, double* Q_dev, const double* f_dev);
+
+/* Same, enqueued on `stream` (a hipStream_t cast to void*; NULL = the handle's own stream) without the final
+ * host synchronisation. */
+int bfsm_collide_async(bfsm_handle h, double* Q_dev, const double* f_dev, void* stream);
+
+/*
+ * Sharded evaluation (new functionality: the reference is single-device).  Every rank calls
+ *   bfsm_gain_partial()  -> this shard's partial Q_gain_hat in the handle-owned buffer bfsm_qhat_buffer()
+ *   <one sum all-reduce / reduce of that buffer: RCCL over xGMI, by the caller>
+ *   bfsm_finish()        -> loss term, final inverse transforms, Q        (cu:193-216)
+ * bfsm_collide() == gain_partial + finish on one device.
+ */
+int bfsm_gain_partial(bfsm_handle h, const double* f_dev, void* stream);
+int bfsm_finish(bfsm_handle h, double* Q_dev, const double* f_dev, void* stream);
+/* Device pointer to the (partial) Q_gain_hat: n_elems reals of `precision` bits (2*G, interleaved complex in the
+ * library's spectral layout [lx][lz][ly]); the buffer the collective must sum in place. */
+void* bfsm_qhat_buffer(bfsm_handle h, size_t* n_elems, int* precision);
+
+/* Blocks until everything enqueued by this handle has completed. */
+int bfsm_synchronize(bfsm_handle h);
+
+/* Batched 3-D complex transform with the library's own kernels (counterpart of the cufftPlanMany plan,
+ * CUDABoltzmannOperator.cu:88-100; used by the FFT unit tests that mirror cufft_benchmark.cu:150-207).
+ * data_dev: batch * G interleaved complex of the handle's precision, transformed in place, unnormalised.
+ * sign -1 = forward: physical [x][y][z] in, spectral-transposed [lx][lz][ly] out (the library's spectral layout);
+ * sign +1 = backward: [lx][lz][ly] in, [x][y][z] out.  batch <= the handle's max_chunk. */
+int bfsm_fft3d(bfsm_handle h, void* data_dev, int batch, int sign);
+
+int bfsm_get_counters(bfsm_handle h, bfsm_counters* out);
+
+/* == ~BoltzmannOperator() (CUDABoltzmannOperator.cu:224-261) */
+int bfsm_destroy(bfsm_handle h);
+
+/* Message of the last failure on this handle (or of the last failed bfsm_create when h == NULL). */
+const char* bfsm_last_error(bfsm_handle h);
+
+/* "HIP" -- what getBackendName() returns (CUDABoltzmannOperator.hpp:60-62 returns "CUDA"). */
+const char* bfsm_backend_name(void);
+int bfsm_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BFSM_H */

@@ -1,0 +1,204 @@
+// bfsm_emu.cpp -- TEST HARNESS ONLY.  Host lock-step emulation of the gfx950 workgroup bodies.
+//
+// There is no GPU in the authoring container, so the index algebra of the kernels (who owns which point, LDS
+// exchange addresses, twiddle indices, layouts, chunk/slab bookkeeping) is unit-tested on the CPU by running the
+// SAME bodies (csrc/bfsm_core.hpp) and the SAME plan + launch sequence (csrc/bfsm_pipeline.hpp) with a backend
+// in which every GPU thread is a ucontext coroutine and __syncthreads() is a yield to a round-robin scheduler.
+// Nothing here is linked into libbfsm_hip.so; the product has no CPU path.
+#define BFSM_HD inline __attribute__((always_inline))
+#include <ucontext.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../boltzmann-fourier-spectral-method_amd/csrc/bfsm_pipeline.hpp"
+
+namespace emu {
+
+struct Sched;
+struct EmuCtx {
+    int tid_, nthreads_, bx_, by_;
+    unsigned char* smem;
+    Sched* sched;
+    int tid() const { return tid_; }
+    int nthreads() const { return nthreads_; }
+    int bx() const { return bx_; }
+    int by() const { return by_; }
+    int uniform(int v, int) const { return v; }
+    template <class U> U* lds() const { return reinterpret_cast<U*>(smem); }
+    void sync();
+};
+
+struct Sched {
+    static constexpr size_t STACK = 256 * 1024;
+    ucontext_t main_ctx;
+    std::vector<ucontext_t> ctxs;
+    std::vector<char> stacks;
+    std::vector<char> done;
+    int current = -1;
+    void (*entry)(void*, EmuCtx&) = nullptr;
+    void* arg = nullptr;
+    std::vector<EmuCtx> ectx;
+
+    static Sched*& active() { static Sched* s = nullptr; return s; }
+    static void trampoline() {
+        Sched* s = active();
+        const int me = s->current;
+        s->entry(s->arg, s->ectx[me]);
+        s->done[me] = 1;
+        swapcontext(&s->ctxs[me], &s->main_ctx);
+    }
+    void yield() { const int me = current; swapcontext(&ctxs[me], &main_ctx); }
+
+    void run_block(int nthreads, int bx, int by, unsigned char* smem, void (*fn)(void*, EmuCtx&), void* a) {
+        entry = fn; arg = a;
+        if ((int)ctxs.size() < nthreads) { ctxs.resize(nthreads); stacks.resize((size_t)nthreads * STACK); }
+        done.assign(nthreads, 0);
+        ectx.resize(nthreads);
+        active() = this;
+        for (int t = 0; t < nthreads; ++t) {
+            ectx[t] = EmuCtx{t, nthreads, bx, by, smem, this};
+            getcontext(&ctxs[t]);
+            ctxs[t].uc_stack.ss_sp = stacks.data() + (size_t)t * STACK;
+            ctxs[t].uc_stack.ss_size = STACK;
+            ctxs[t].uc_link = &main_ctx;
+            makecontext(&ctxs[t], (void (*)())trampoline, 0);
+        }
+        int remaining = nthreads;
+        while (remaining > 0) {   // one round = every live thread runs up to its next barrier (or to its end)
+            for (int t = 0; t < nthreads; ++t) {
+                if (done[t]) continue;
+                current = t;
+                swapcontext(&main_ctx, &ctxs[t]);
+                if (done[t]) --remaining;
+            }
+        }
+    }
+};
+inline void EmuCtx::sync() { sched->yield(); }
+
+struct EmuBackend {
+    Sched sched;
+    std::vector<unsigned char> smem;
+    void* alloc(size_t bytes) { return std::calloc(1, bytes); }
+    void release(void* p) { std::free(p); }
+    void upload(void* dst, const void* src, size_t bytes) { std::memcpy(dst, src, bytes); }
+    void mark(int, double) {}
+
+    template <bfsm::K kind, int N, typename T, class P>
+    static void body(void* a, EmuCtx& ctx) {
+        using namespace bfsm;
+        const P& prm = *static_cast<const P*>(a);
+        if constexpr (kind == K::TileFwdReal) body_tile_fwd_real<N, T>(prm, ctx);
+        else if constexpr (kind == K::LineFwd) body_line<N, -1, T>(prm, ctx);
+        else if constexpr (kind == K::LineInv) body_line<N, +1, T>(prm, ctx);
+        else if constexpr (kind == K::TileFwd) body_tile_c2c<N, -1, T>(prm, ctx);
+        else if constexpr (kind == K::TileInv) body_tile_c2c<N, +1, T>(prm, ctx);
+        else if constexpr (kind == K::GainInv) body_gain_inv<N, T>(prm, ctx);
+        else if constexpr (kind == K::GainLine) body_gain_line<N, T>(prm, ctx);
+        else if constexpr (kind == K::GainFwd) body_gain_fwd<N, T>(prm, ctx);
+        else if constexpr (kind == K::Reduce) body_reduce<N, T>(prm, ctx);
+        else if constexpr (kind == K::TailInv) body_tail_inv<N, T>(prm, ctx);
+        else if constexpr (kind == K::TailLine) body_tail_line<N, T>(prm, ctx);
+    }
+
+    template <bfsm::K kind, int N, typename T, class P>
+    void launch_n(int gx, int gy, const P& prm) {
+        const int threads = kind == bfsm::K::Reduce ? 256 : bfsm::Wg<N>::THREADS;
+        smem.assign((size_t)bfsm::Wg<N>::LDS_ELEMS * sizeof(bfsm::cx<T>), 0xCD);
+        P copy = prm;
+        for (int by = 0; by < gy; ++by)
+            for (int bx = 0; bx < gx; ++bx)
+                sched.run_block(threads, bx, by, smem.data(), &body<kind, N, T, P>, &copy);
+    }
+
+    template <bfsm::K kind, typename T, class P>
+    void launch(int gx, int gy, const P& prm, int N) {
+        switch (N) {
+            case 16: launch_n<kind, 16, T>(gx, gy, prm); break;
+            case 32: launch_n<kind, 32, T>(gx, gy, prm); break;
+            case 64: launch_n<kind, 64, T>(gx, gy, prm); break;
+            case 128:
+                if constexpr (sizeof(T) == 4) launch_n<kind, 128, T>(gx, gy, prm);
+                break;
+            default: break;
+        }
+    }
+};
+
+template <typename T>
+int collide_t(const bfsm_desc* d, const double* f, double* Q, double* qhat_out) {
+    EmuBackend be;
+    bfsm::Pipeline<T, EmuBackend> p;
+    std::string err;
+    int rc = p.init(*d, &be, err);
+    if (rc) return rc;
+    p.gain_partial(f);
+    if (qhat_out) {
+        const size_t G = p.plan.G();
+        for (size_t i = 0; i < G; ++i) { qhat_out[2 * i] = (double)p.qhat[i].x; qhat_out[2 * i + 1] = (double)p.qhat[i].y; }
+    }
+    if (Q) p.finish(Q, f);
+    p.destroy();
+    return 0;
+}
+
+template <typename T>
+int fft3d_t(int N, double* data, int batch, int sign) {
+    EmuBackend be;
+    bfsm::Pipeline<T, EmuBackend> p;
+    p.be = &be;
+    p.plan.N = N;
+    std::vector<bfsm::cx<T>> tw(N);
+    const long double PI_L = 3.141592653589793238462643383279502884L;
+    for (int n = 0; n < N; ++n) {
+        const long double a = -2.0L * PI_L * n / N;
+        tw[n] = {(T)cosl(a), (T)sinl(a)};
+    }
+    p.tw = tw.data();
+    const size_t total = (size_t)batch * N * N * N;
+    std::vector<bfsm::cx<T>> buf(total);
+    for (size_t i = 0; i < total; ++i) buf[i] = {(T)data[2 * i], (T)data[2 * i + 1]};
+    p.fft3d(buf.data(), batch, sign);
+    for (size_t i = 0; i < total; ++i) { data[2 * i] = (double)buf[i].x; data[2 * i + 1] = (double)buf[i].y; }
+    p.tw = nullptr;
+    return 0;
+}
+
+}  // namespace emu
+
+extern "C" {
+
+// Emulated bfsm_gain_partial + bfsm_finish on host arrays.  qhat_out (optional): 2*G doubles, spectral layout
+// [lx][lz][ly].  Q may be NULL to skip the tail.
+int bfsm_emu_collide(const bfsm_desc* d, const double* f, double* Q, double* qhat_out) {
+    std::string err;
+    int rc = bfsm::validate_desc(*d, err);
+    if (rc) return rc;
+    return d->precision == BFSM_F64 ? emu::collide_t<double>(d, f, Q, qhat_out) : emu::collide_t<float>(d, f, Q, qhat_out);
+}
+
+// Emulated bfsm_fft3d; data = batch*G interleaved complex doubles (narrowed to float when precision == 32).
+int bfsm_emu_fft3d(int N, int precision, double* data, int batch, int sign) {
+    if (N != 16 && N != 32 && N != 64 && N != 128) return BFSM_ERR_UNSUPPORTED;
+    if (precision == BFSM_F64) { if (N == 128) return BFSM_ERR_UNSUPPORTED; return emu::fft3d_t<double>(N, data, batch, sign); }
+    return emu::fft3d_t<float>(N, data, batch, sign);
+}
+
+// Plan introspection for the host-logic tests: fills chunk (r, dir0, n, per_group, slab0) rows, returns the count.
+int bfsm_emu_plan(const bfsm_desc* d, int* rows, int max_rows, int* groups) {
+    std::string err;
+    int rc = bfsm::validate_desc(*d, err);
+    if (rc) return -rc;
+    bfsm::PlanInfo p = bfsm::make_plan(*d);
+    if (groups) *groups = p.groups;
+    int n = 0;
+    for (const auto& c : p.chunks) {
+        if (n < max_rows) { rows[5 * n] = c.r; rows[5 * n + 1] = (int)c.dir0; rows[5 * n + 2] = c.n; rows[5 * n + 3] = c.per_group; rows[5 * n + 4] = c.slab0; }
+        ++n;
+    }
+    return n;
+}
+}

@@ -1,0 +1,80 @@
+"""ctypes access to tests/emu/libbfsm_emu.so -- the host lock-step emulation of the HIP kernel bodies (test harness)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        subprocess.check_call(["make", "-C", os.path.join(_HERE, "emu"), "-s"])
+        from bfsm import capi
+        L = ctypes.CDLL(os.path.join(_HERE, "emu", "libbfsm_emu.so"))
+        dp = ctypes.POINTER(ctypes.c_double)
+        L.bfsm_emu_collide.argtypes = [ctypes.POINTER(capi.Desc), dp, dp, dp]
+        L.bfsm_emu_collide.restype = ctypes.c_int
+        L.bfsm_emu_fft3d.argtypes = [ctypes.c_int, ctypes.c_int, dp, ctypes.c_int, ctypes.c_int]
+        L.bfsm_emu_fft3d.restype = ctypes.c_int
+        L.bfsm_emu_plan.argtypes = [ctypes.POINTER(capi.Desc), ctypes.POINTER(ctypes.c_int), ctypes.c_int,
+                                    ctypes.POINTER(ctypes.c_int)]
+        L.bfsm_emu_plan.restype = ctypes.c_int
+        _LIB = L
+    return _LIB
+
+
+def make_desc(nv, gl, sph, gamma, b_gamma, L, precision=64, dir_range=(0, 0), max_chunk=0):
+    """gl = (nodes, weights), sph = (x, y, z, w).  Returns (Desc, keepalive)."""
+    from bfsm import capi
+    dp = ctypes.POINTER(ctypes.c_double)
+    keep = [np.ascontiguousarray(a, dtype=np.float64) for a in (gl[0], gl[1], sph[3], sph[0], sph[1], sph[2])]
+    d = capi.Desc(nv, nv, nv, len(keep[0]), len(keep[2]), *[a.ctypes.data_as(dp) for a in keep],
+                  gamma, b_gamma, L, precision, 0, dir_range[0], dir_range[1], max_chunk, 0)
+    return d, keep
+
+
+def collide(f, gl, sph, gamma, b_gamma, L, precision=64, dir_range=(0, 0), max_chunk=0, want_Q=True):
+    nv = f.shape[0]
+    d, keep = make_desc(nv, gl, sph, gamma, b_gamma, L, precision, dir_range, max_chunk)
+    f = np.ascontiguousarray(f, dtype=np.float64)
+    Q = np.empty_like(f)
+    qh = np.empty(f.shape + (2,))
+    dp = ctypes.POINTER(ctypes.c_double)
+    rc = lib().bfsm_emu_collide(ctypes.byref(d), f.ctypes.data_as(dp), Q.ctypes.data_as(dp) if want_Q else None,
+                                qh.ctypes.data_as(dp))
+    if rc:
+        raise RuntimeError(f"bfsm_emu_collide rc={rc}")
+    qhat_t = qh[..., 0] + 1j * qh[..., 1]            # [lx][lz][ly]
+    return (Q if want_Q else None), np.ascontiguousarray(qhat_t.transpose(0, 2, 1))   # -> [lx][ly][lz]
+
+
+def fft3d(a, sign, precision=64):
+    """a: [batch][N][N][N] complex.  forward: natural in, natural out (un-transposed here); backward likewise."""
+    a = np.ascontiguousarray(a, dtype=np.complex128)
+    batch, n = a.shape[0], a.shape[1]
+    if sign > 0:
+        a = np.ascontiguousarray(a.transpose(0, 1, 3, 2))       # natural spectral -> [lx][lz][ly]
+    buf = a.copy()
+    dp = ctypes.POINTER(ctypes.c_double)
+    rc = lib().bfsm_emu_fft3d(n, precision, buf.view(np.float64).ctypes.data_as(dp), batch, sign)
+    if rc:
+        raise RuntimeError(f"bfsm_emu_fft3d rc={rc}")
+    if sign < 0:
+        buf = np.ascontiguousarray(buf.transpose(0, 1, 3, 2))   # [lx][lz][ly] -> natural
+    return buf
+
+
+def plan(nv, n_gl, n_sph, precision=64, dir_range=(0, 0), max_chunk=0):
+    gl = (np.ones(n_gl), np.ones(n_gl))
+    sph = (np.ones(n_sph), np.zeros(n_sph), np.zeros(n_sph), np.ones(n_sph))
+    d, keep = make_desc(nv, gl, sph, 0.0, 1.0, 1.0, precision, dir_range, max_chunk)
+    rows = (ctypes.c_int * (5 * 4096))()
+    groups = ctypes.c_int()
+    n = lib().bfsm_emu_plan(ctypes.byref(d), rows, 4096, ctypes.byref(groups))
+    if n < 0:
+        raise ValueError(f"plan rejected rc={-n}")
+    return [tuple(rows[5 * i:5 * i + 5]) for i in range(n)], groups.value

@@ -1,0 +1,68 @@
+"""The C-ABI library loads on a machine without a GPU and exports every symbol include/bfsm.h declares."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "boltzmann-fourier-spectral-method_amd")
+
+
+@pytest.fixture(scope="module")
+def libpath():
+    so = os.path.join(PKG, "libbfsm_hip.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", PKG, "-s", "libbfsm_hip.so"])
+    return so
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "bfsm.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(bfsm_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported(libpath):
+    from bfsm import capi
+    declared = _declared_symbols()
+    assert declared == sorted(capi.EXPORTED_SYMBOLS)
+    L = ctypes.CDLL(libpath)
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+def test_no_compute_entry_points_without_gpu_but_metadata_works(libpath):
+    from bfsm import capi
+    L = capi.load_library()
+    assert L.bfsm_backend_name() == b"HIP"
+    assert L.bfsm_version() == 1
+
+
+def test_descriptor_validation_errors_are_reported(libpath):
+    """Error behaviour of the boundary: status code + message, never an exit (the C++ wrapper adds print-and-exit)."""
+    import numpy as np
+    from bfsm import capi
+    L = capi.load_library()
+    one = np.ones(4)
+    dp = ctypes.POINTER(ctypes.c_double)
+    p = one.ctypes.data_as(dp)
+    h = ctypes.c_void_p()
+    bad_n = capi.Desc(48, 48, 48, 4, 4, p, p, p, p, p, p, 0.0, 1.0, 1.0, 64, 0, 0, 0, 0, 0)
+    assert L.bfsm_create(ctypes.byref(bad_n), ctypes.byref(h)) == 2
+    assert b"16, 32, 64, 128" in L.bfsm_last_error(None)
+    bad_prec = capi.Desc(128, 128, 128, 4, 4, p, p, p, p, p, p, 0.0, 1.0, 1.0, 64, 0, 0, 0, 0, 0)
+    assert L.bfsm_create(ctypes.byref(bad_prec), ctypes.byref(h)) == 2
+    bad_shard = capi.Desc(16, 16, 16, 4, 4, p, p, p, p, p, p, 0.0, 1.0, 1.0, 64, 0, 3, 99, 0, 0)
+    assert L.bfsm_create(ctypes.byref(bad_shard), ctypes.byref(h)) == 1
+    assert L.bfsm_create(None, ctypes.byref(h)) == 1
+
+
+def test_product_never_references_the_oracle():
+    """oracle/ is test infrastructure: nothing under the package may import, link or call it."""
+    for dirpath, _, files in os.walk(PKG):
+        for fn in files:
+            if fn.endswith((".py", ".hpp", ".hip", ".cpp", ".h", "Makefile")):
+                text = open(os.path.join(dirpath, fn), errors="ignore").read()
+                assert "oracle" not in text.lower().replace("test infrastructure", ""), os.path.join(dirpath, fn)

@@ -1,0 +1,103 @@
+"""CPU unit tests of the HIP kernel bodies through the host lock-step emulator (tests/emu).
+
+The emulator runs the exact device code of csrc/bfsm_core.hpp (every GPU thread a coroutine, __syncthreads a
+yield) under the exact plan + launch sequence of csrc/bfsm_pipeline.hpp, so layouts, LDS exchange addresses,
+twiddles, chunking and slab bookkeeping are checked against the oracle without a GPU.  The -m gpu tests then only
+have to confirm that the hardware executes the same code.
+"""
+import numpy as np
+import pytest
+
+import emu_lib as E
+
+GAMMA, B_GAMMA, R = 0.0, 1.0 / (4.0 * np.pi), 10.0
+
+
+@pytest.mark.parametrize("n,prec,tol", [(16, 64, 2e-15), (32, 64, 2e-15), (64, 64, 3e-15), (16, 32, 1e-6),
+                                        (32, 32, 1e-6), (64, 32, 1e-6), (128, 32, 1e-6)])
+def test_fft3d_matches_numpy_and_round_trips(n, prec, tol):
+    """Mirrors the reference's FFT check (fftw_benchmark.cpp:137-171): forward, scale 1/G, inverse."""
+    rng = np.random.default_rng(n + prec)
+    batch = 1 if n >= 64 else 2
+    a = rng.standard_normal((batch, n, n, n)) + 1j * rng.standard_normal((batch, n, n, n))
+    ref = np.fft.fftn(a, axes=(1, 2, 3))
+    fw = E.fft3d(a, -1, prec)
+    assert np.abs(fw - ref).max() <= tol * np.abs(ref).max()
+    back = E.fft3d(ref, +1, prec) / n ** 3
+    assert np.abs(back - a).max() <= tol * np.abs(a).max()
+
+
+@pytest.mark.parametrize("nv,n_gl,n_sph,max_chunk,prec,tol", [
+    (16, 2, 6, 0, 64, 1e-12), (16, 3, 12, 5, 64, 1e-12), (32, 2, 6, 4, 64, 1e-12), (16, 2, 6, 0, 32, 2e-5),
+])
+def test_collide_matches_oracle(oracle, nv, n_gl, n_sph, max_chunk, prec, tol):
+    f, _, L, _ = oracle.bkw(nv)
+    f = oracle.perturbed_input(f)          # non-symmetric: exercises the Nyquist planes
+    gl = oracle.gauss_legendre(n_gl, 0.0, R)
+    sph = oracle.spherical_design(n_sph)
+    Q, qhat = E.collide(f, gl, sph, GAMMA, B_GAMMA, L, prec, max_chunk=max_chunk)
+    Qo, qo = oracle.collide(f, gl, sph, GAMMA, B_GAMMA, L, return_qhat=True)
+    assert np.abs(qhat - qo).max() <= tol * np.abs(qo).max()
+    assert np.abs(Q - Qo).max() <= tol * np.abs(Qo).max()
+
+
+@pytest.mark.slow
+def test_collide_n64_matches_oracle(oracle):
+    f, _, L, _ = oracle.bkw(64)
+    f = oracle.perturbed_input(f)
+    gl = oracle.gauss_legendre(2, 0.0, R)
+    sph = oracle.spherical_design(6)
+    Q, qhat = E.collide(f, gl, sph, GAMMA, B_GAMMA, L, 64, max_chunk=4)
+    Qo, qo = oracle.collide(f, gl, sph, GAMMA, B_GAMMA, L, return_qhat=True)
+    assert np.abs(qhat - qo).max() <= 1e-12 * np.abs(qo).max()
+    assert np.abs(Q - Qo).max() <= 1e-12 * np.abs(Qo).max()
+
+
+def test_direction_shards_add_up(oracle):
+    """Partial Q_gain_hat of disjoint shards (what each GPU contributes to the reduce) sums to the whole."""
+    f, _, L, _ = oracle.bkw(16)
+    f = oracle.perturbed_input(f)
+    gl = oracle.gauss_legendre(3, 0.0, R)
+    sph = oracle.spherical_design(12)
+    _, whole = oracle.collide(f, gl, sph, GAMMA, B_GAMMA, L, return_qhat=True)
+    parts = 0
+    for rng_ in ((0, 7), (7, 20), (20, 36)):
+        _, qh = E.collide(f, gl, sph, GAMMA, B_GAMMA, L, 64, dir_range=rng_, max_chunk=5, want_Q=False)
+        po = oracle.collide(f, gl, sph, GAMMA, B_GAMMA, L, dir_range=rng_, return_qhat=True)[1]
+        assert np.abs(qh - po).max() <= 1e-12 * np.abs(whole).max()
+        parts = parts + qh
+    assert np.abs(parts - whole).max() <= 1e-12 * np.abs(whole).max()
+
+
+def test_empty_shard_gives_zero_gain(oracle):
+    f, _, L, _ = oracle.bkw(16)
+    gl = oracle.gauss_legendre(2, 0.0, R)
+    sph = oracle.spherical_design(6)
+    _, qh = E.collide(f, gl, sph, GAMMA, B_GAMMA, L, 64, dir_range=(5, 5), want_Q=False)
+    assert np.all(qh == 0)
+
+
+def test_plan_chunks_cover_shard_once():
+    """Host logic: chunks never straddle a radial node, respect max_chunk, tile the shard exactly."""
+    for nv, n_gl, n_sph, rng_, mc in [(64, 16, 48, (0, 0), 0), (64, 16, 156, (0, 0), 0), (128, 30, 192, (0, 0), 0),
+                                      (64, 16, 156, (312, 624), 0), (16, 3, 12, (7, 20), 5), (32, 8, 48, (0, 0), 7)]:
+        prec = 32 if nv == 128 else 64
+        chunks, groups = E.plan(nv, n_gl, n_sph, prec, rng_, mc)
+        b0, b1 = rng_ if rng_ != (0, 0) else (0, n_gl * n_sph)
+        cap = mc or 64
+        pos = 0
+        for i, (r, d0, n, per_group, slab0) in enumerate(chunks):
+            assert d0 == pos and 1 <= n <= cap
+            assert (b0 + d0) // n_sph == r == (b0 + d0 + n - 1) // n_sph
+            assert per_group * groups >= n and slab0 == i * groups
+            pos += n
+        assert pos == b1 - b0
+
+
+def test_plan_rejects_unsupported():
+    with pytest.raises(ValueError):
+        E.plan(48, 2, 6)
+    with pytest.raises(ValueError):
+        E.plan(128, 2, 6, 64)            # N=128 needs fp32
+    with pytest.raises(ValueError):
+        E.plan(16, 2, 6, 64, (5, 40))    # shard beyond n_gl*n_sph
