@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py -- collision-operator evaluations per second on N MI355X GPUs (BASELINE.json's metric).
+
+A "step" is one evaluation Q = Q(f,f) of the Fourier-spectral Boltzmann collision operator on a synthetic f
+(the BKW distribution of the reference drivers, maxwell_bkw_cuda.cu:81-107) that is resident in HBM before the timed
+region starts, through the C-ABI of libbfsm_hip.so -- exactly what `collision_operator(Q, f_bkw)` times in the
+reference driver (maxwell_bkw_cuda.cu:144-151).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+N > 1: the B = M_gl*M_sph quadrature directions are sharded contiguously over the ranks (strong scaling: the
+workload is fixed), each rank computes its partial Q_gain_hat, ONE RCCL all-reduce (torch.distributed "nccl")
+sums it over xGMI, every rank finishes the O(G) tail redundantly.
+
+Workloads (BASELINE.json configs):  cfg2 N=32,M_gl=8,ss009.048 | cfg3 N=64,M_gl=16,ss009.048 (default, the
+roofline configuration) | cfg4 N=64,M_gl=16,ss017.156 | cfg5 N=128,M_gl=30,ss019.192 fp32.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "boltzmann-fourier-spectral-method_amd"))
+
+WORKLOADS = {
+    "cfg1": dict(nv=16, n_gl=8, n_sph=32, precision=64, design="ss007.032"),
+    "cfg2": dict(nv=32, n_gl=8, n_sph=48, precision=64, design="ss009.048"),
+    "cfg3": dict(nv=64, n_gl=16, n_sph=48, precision=64, design="ss009.048"),
+    "cfg4": dict(nv=64, n_gl=16, n_sph=156, precision=64, design="ss017.156"),
+    "cfg5": dict(nv=128, n_gl=30, n_sph=192, precision=32, design="ss019.192"),
+}
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling there: 6290 GB/s
+
+
+def _dev_view(torch, ptr, n, prec):
+    class V:
+        pass
+    v = V()
+    v.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8" if prec == 64 else "<f4",
+                                  "data": (int(ptr), False), "version": 2}
+    return torch.as_tensor(v, device="cuda")
+
+
+def cpu_baseline(w, seconds_target=15.0):
+    """The oracle (CPU restatement of the reference's FFTW path, kind "port") timed on this box's host cores on a
+    bounded sample: the first n_sample directions of the same workload, all OpenMP threads."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import oracle as O
+    import bfsm
+    c = bfsm.reference_constants()
+    f_h = bfsm.bkw_solution(w["nv"])[0]
+    gl = O.gauss_legendre(w["n_gl"], 0.0, c["R"])
+    sph = O.spherical_design(w["n_sph"])
+    B = w["n_gl"] * w["n_sph"]
+    threads = O.lib().bfsm_oracle_threads()
+    n = min(B, max(2 * threads, 8))
+    t0 = time.perf_counter()
+    O.collide(f_h, gl, sph, c["gamma"], c["b_gamma"], c["L"], dir_range=(0, n))
+    t1 = time.perf_counter() - t0
+    # scale the sample up once if it was very short, to get ~seconds_target of CPU work
+    if t1 < seconds_target / 4 and n < B:
+        n2 = int(min(B, max(n, n * (seconds_target / max(t1, 1e-3)) * 0.8)))
+        n2 = max(threads, (n2 // threads) * threads)
+        t0 = time.perf_counter()
+        O.collide(f_h, gl, sph, c["gamma"], c["b_gamma"], c["L"], dir_range=(0, n2))
+        t1, n = time.perf_counter() - t0, n2
+    evals_per_s = (n / B) / t1
+    return {"value": evals_per_s, "unit": "evals/s", "cores": threads, "kind": "port",
+            "sample": f"oracle/bfsm_oracle.c (own radix-2 FFT, fp64), first {n} of {B} directions of the same workload "
+                      f"in {t1:.2f} s on {threads} OpenMP threads, extrapolated linearly to B; FFTW3 is not installed "
+                      f"in this image"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--max-chunk", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import bfsm
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the collision operator has no CPU path", file=sys.stderr)
+        sys.exit(3)
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    w = WORKLOADS[args.workload]
+    nv, n_gl, n_sph, prec = w["nv"], w["n_gl"], w["n_sph"], w["precision"]
+    B = n_gl * n_sph
+    c = bfsm.reference_constants()
+    f_h = bfsm.bkw_solution(nv)[0]
+
+    def make(profile):
+        op = bfsm.HIPBoltzmannOperator(bfsm.GaussLegendreQuadrature(n_gl, 0.0, c["R"]), bfsm.SphericalDesign(n_sph),
+                                       nv, nv, nv, c["gamma"], c["b_gamma"], c["L"])
+        op.setPrecision(prec)
+        op.setDevice(local_rank)
+        if world > 1:
+            op.setDirectionShard(*bfsm.shard_range(B, rank, world))
+        if args.max_chunk:
+            op.setMaxChunk(args.max_chunk)
+        op.setProfiling(profile)
+        op.initialize()
+        return op
+
+    op = make(False)
+    f = torch.from_numpy(f_h).cuda()
+    Q = torch.empty_like(f)
+    qhat = _dev_view(torch, *op.qhatBuffer()) if world > 1 else None
+
+    def step():
+        s = torch.cuda.current_stream().cuda_stream
+        if world == 1:
+            op.computeCollisionAsync(Q, f, s)
+        else:
+            op.gainPartial(f, s)
+            dist.all_reduce(qhat)                 # the single RCCL collective of an evaluation
+            op.finish(Q, f, s)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    evals_per_s = args.steps / elapsed
+    cbytes = 16.0 if prec == 64 else 8.0
+    alg_bytes = (6.0 * B + 9.0) * nv ** 3 * cbytes            # whole evaluation, all GPUs
+    alg_gbps = alg_bytes / (elapsed / args.steps) / 1e9
+
+    roofline = None
+    if not args.no_roofline:
+        # dominant kernel, timed live with HIP events on the stream it is launched on (BFSM_FLAG_PROFILE)
+        opp = make(True)
+        s = torch.cuda.current_stream().cuda_stream
+        for _ in range(2):
+            opp.gainPartial(f, s)
+            opp.finish(Q, f, s)
+        torch.cuda.synchronize()
+        reps, acc = 5, None
+        for _ in range(reps):
+            opp.gainPartial(f, s)
+            opp.finish(Q, f, s)
+            torch.cuda.synchronize()
+            cn = opp.counters()
+            cur = [(cn.kernel_ms[i], cn.kernel_alg_bytes[i], cn.kernel_launches[i]) for i in range(len(bfsm.KERNEL_NAMES))]
+            acc = cur if acc is None else [(a[0] + b[0], a[1] + b[1], a[2] + b[2]) for a, b in zip(acc, cur)]
+        opp.destroy()
+        dom = max(range(len(acc)), key=lambda i: acc[i][0])
+        ms, nbytes, launches = acc[dom]
+        achieved = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(bfsm.KERNEL_NAMES[dom], {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": bfsm.KERNEL_NAMES[dom], "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                    "alg_bytes_per_launch": nbytes / max(launches, 1), "avg_launch_ms": ms / max(launches, 1),
+                    "launches_per_eval": launches // reps,
+                    "per_kernel": {bfsm.KERNEL_NAMES[i]: {"ms_per_eval": acc[i][0] / reps,
+                                                          "alg_GBps": (acc[i][1] / (acc[i][0] * 1e-3) / 1e9) if acc[i][0] > 0 else 0.0}
+                                   for i in range(len(acc))}}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(w)
+
+    op.destroy()
+    if rank == 0:
+        out = {
+            "metric": "collision-operator evals/sec", "value": evals_per_s, "unit": "evals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64" if prec == 64 else "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: N={nv}^3 grid, M_gl={n_gl}, {w['design']} ({n_sph} pts), "
+                                   f"B={B} directions, BKW f (t=6.5), Maxwell molecules",
+                       "directions_per_gpu": B // world, "parallelism": f"direction-shard x{world} + 1 all-reduce"},
+            "achieved_alg_GBps": alg_gbps, "frac_of_hbm_peak": alg_gbps / (HBM_PEAK_GBPS * world),
+            "alg_bytes_per_eval": alg_bytes,
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

