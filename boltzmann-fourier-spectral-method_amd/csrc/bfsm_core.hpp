@@ -211,27 +211,34 @@ struct GainLineParams {      // KB
     const cx<T>* tw;
 };
 
-template <typename T>
-struct GainFwdParams {       // KC
-    const cx<T>* p;          // [slot][x][y][z]
-    cx<T>* slab;             // [chunk_slab0 + group][lx][lz][ly]
-    const T* dirw;           // [B] scalar weight of direction b: (1/G) w_r w_s rho_r^(gamma+2)
-    const cx<T>* tw;
-    long long dir0;
-    int n_dir;
-    int per_group;
-    int slab0;               // first slab index of this chunk
+// One accumulating workgroup column of KC: a run of directions that all share the radial node r, so that beta1
+// (which depends on r and |l|^2 only) can be applied once per slab by body_reduce instead of per direction.
+struct Segment {
+    int d0;                  // first direction, relative to the chunk
+    int n;                   // directions in the segment
+    int r;                   // radial node
+    int pad;
 };
 
 template <typename T>
-struct ReduceParams {        // Q_hat[l] = sum_chunks beta1[r(chunk)][|l|^2] * sum_groups slab
+struct GainFwdParams {       // KC
+    const cx<T>* p;          // [slot][x][y][z]
+    cx<T>* slab;             // [segment][lx][lz][ly]: sum over the segment of dirw * P_hat (beta1 not yet applied)
+    const T* dirw;           // [n_dirs] scalar weight of direction b: (1/G) w_r w_s rho_r^(gamma+2)
+    const Segment* segs;     // [n_segments] of the whole plan
+    const cx<T>* tw;
+    long long dir0;          // shard-local index of the chunk's first direction
+    int seg0;                // first segment of this chunk (== its first slab)
+};
+
+template <typename T>
+struct ReduceParams {        // Q_hat[l] = sum_segments beta1[r(seg)][|l|^2] * slab[seg][l]   (fixed order)
     const cx<T>* slab;
     cx<T>* qhat;             // [lx][lz][ly]
-    const T* beta1;          // [M_gl][n2max+1]: 4 pi b_gamma sincc(pi rho_r sqrt(n2) / (2L))
-    const int* chunk_r;      // [n_chunks]
-    int n_chunks;
-    int groups;              // slabs per chunk
-    int n2stride;            // n2max + 1
+    const T* beta1;          // [M_gl][n2stride]: 4 pi b_gamma sincc(pi rho_r sqrt(n2) / (2L))
+    const Segment* segs;
+    int n_segs;
+    int n2stride;            // 3 (N/2)^2 + 1
 };
 
 template <typename T>
@@ -368,9 +375,9 @@ BFSM_HD void body_gain_line(const GainLineParams<T>& prm, Ctx& ctx) {
     for (int m = 0; m < E; ++m) prm.a1[base + (size_t)(u + TT * m) * N * N] = a[m];
 }
 
-// KC.  grid = (N planes x, groups).  (y,z) part of the forward transform + the direction sum of
-// atomic_tensor_contraction (BoltzmannCUDAKernels.cu:79-123) kept in registers: no atomics, one slab store.
-// beta1 depends on the radial node only, so it is applied once per chunk by body_reduce.
+// KC.  grid = (N planes x, segments of the chunk).  (y,z) part of the forward transform + the direction sum of
+// atomic_tensor_contraction (BoltzmannCUDAKernels.cu:79-123) kept in registers: no atomics, one slab store per
+// workgroup.  A segment never straddles a radial node, so beta1 is applied later, once per slab.
 template <int N, typename T, class Ctx>
 BFSM_HD void body_gain_fwd(const GainFwdParams<T>& prm, Ctx& ctx) {
     constexpr int E = Wg<N>::E, TT = Wg<N>::T;
@@ -380,10 +387,8 @@ BFSM_HD void body_gain_fwd(const GainFwdParams<T>& prm, Ctx& ctx) {
     cx<T> acc[E];
 #pragma unroll
     for (int m = 0; m < E; ++m) acc[m] = {(T)0, (T)0};
-    const int d_begin = ctx.by() * prm.per_group;
-    int d_end = d_begin + prm.per_group;
-    if (d_end > prm.n_dir) d_end = prm.n_dir;
-    for (int d = d_begin; d < d_end; ++d) {
+    const Segment seg = prm.segs[prm.seg0 + ctx.by()];
+    for (int d = seg.d0; d < seg.d0 + seg.n; ++d) {
         const cx<T>* src = prm.p + ((size_t)d * N + x) * N * N;
         cx<T> v[E];
 #pragma unroll
@@ -396,13 +401,13 @@ BFSM_HD void body_gain_fwd(const GainFwdParams<T>& prm, Ctx& ctx) {
             acc[m].y += w * v[m].y;
         }
     }
-    cx<T>* dst = prm.slab + ((size_t)(prm.slab0 + ctx.by()) * N + x) * N * N;
+    cx<T>* dst = prm.slab + ((size_t)(prm.seg0 + ctx.by()) * N + x) * N * N;
 #pragma unroll
     for (int m = 0; m < E; ++m) dst[(u + TT * m) * N + p] = acc[m];   // [lz = u + T m][ly = p]
 }
 
-// Reduce.  One thread per spectral point, grid.x * blockDim = G.  Applies beta1 (the per-point part of
-// BoltzmannCUDAKernels.cu:113-114) and sums the write-once slabs in a fixed order (deterministic).
+// Reduce.  One thread per spectral point.  Applies beta1 (the per-point factor of BoltzmannCUDAKernels.cu:113-114)
+// and sums the write-once slabs in a fixed order (deterministic; replaces the atomicAdd pair of cu:120-121).
 template <int N, typename T, class Ctx>
 BFSM_HD void body_reduce(const ReduceParams<T>& prm, Ctx& ctx) {
     const size_t G = (size_t)N * N * N;
@@ -412,16 +417,11 @@ BFSM_HD void body_reduce(const ReduceParams<T>& prm, Ctx& ctx) {
     const int mx = mode_of(lx, N), my = mode_of(ly, N), mz = mode_of(lz, N);
     const int n2 = mx * mx + my * my + mz * mz;
     cx<T> q = {(T)0, (T)0};
-    for (int c = 0; c < prm.n_chunks; ++c) {
-        cx<T> s = {(T)0, (T)0};
-        for (int g = 0; g < prm.groups; ++g) {
-            const cx<T> t = prm.slab[(size_t)(c * prm.groups + g) * G + idx];
-            s.x += t.x;
-            s.y += t.y;
-        }
-        const T b1 = prm.beta1[(size_t)prm.chunk_r[c] * prm.n2stride + n2];
-        q.x += b1 * s.x;
-        q.y += b1 * s.y;
+    for (int c = 0; c < prm.n_segs; ++c) {
+        const cx<T> t = prm.slab[(size_t)c * G + idx];
+        const T b1 = prm.beta1[(size_t)prm.segs[c].r * prm.n2stride + n2];
+        q.x += b1 * t.x;
+        q.y += b1 * t.y;
     }
     prm.qhat[idx] = q;
 }

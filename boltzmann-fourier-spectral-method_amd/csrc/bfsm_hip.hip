@@ -31,8 +31,13 @@ struct DevCtx {
 template <K kind, int N>
 constexpr int kernel_threads() { return kind == K::Reduce ? 256 : Wg<N>::THREADS; }
 
+// Minimum waves per SIMD the register allocator must leave room for.  N=64: a 512-thread workgroup is 2 waves per
+// SIMD and its 65 KiB tile lets two workgroups share a CU's 160 KiB LDS, so ask for 4 (<= 128 VGPRs).
+template <K kind, int N>
+constexpr int kernel_min_waves() { return (kind != K::Reduce && N == 64) ? 4 : 1; }
+
 template <K kind, int N, typename T, class P>
-__global__ void __launch_bounds__((kernel_threads<kind, N>())) bfsm_kernel(const P prm) {
+__global__ void __launch_bounds__((kernel_threads<kind, N>()), (kernel_min_waves<kind, N>())) bfsm_kernel(const P prm) {
     extern __shared__ __align__(16) unsigned char bfsm_smem[];
     DevCtx ctx{bfsm_smem};
     if constexpr (kind == K::TileFwdReal) body_tile_fwd_real<N, T>(prm, ctx);

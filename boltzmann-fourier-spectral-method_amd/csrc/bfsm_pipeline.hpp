@@ -23,11 +23,11 @@
 namespace bfsm {
 
 struct Chunk {
-    int r;            // radial node shared by all directions of the chunk (beta1 depends on r only)
     long long dir0;   // first direction, LOCAL index inside the shard (tables are shard-local)
-    int n;            // directions in the chunk
-    int per_group;    // directions per accumulating workgroup
-    int slab0;        // first slab of the chunk
+    int n;            // directions in the chunk (may span several radial nodes)
+    int per_group;    // directions per workgroup column of KA
+    int seg0;         // first accumulation segment (== first slab) of the chunk
+    int n_seg;        // segments of the chunk (grid.y of KC)
 };
 
 struct PlanInfo {
@@ -35,8 +35,9 @@ struct PlanInfo {
     int precision = 64;
     int n_gl = 0, n_sph = 0;
     long long dir_begin = 0, dir_end = 0;  // global direction range of the shard
-    int max_chunk = 64;
-    int groups = 8;                        // accumulating workgroups per x-plane (slabs per chunk)
+    int max_chunk = 1024;
+    int groups = 8;                        // target workgroup columns per x-plane (>= 2 workgroups per CU)
+    std::vector<Segment> segs;             // accumulation segments of all chunks, in slab order
     int n2stride = 0;                      // 3*(N/2)^2 + 1
     std::vector<Chunk> chunks;
     int largest_chunk = 0;
@@ -76,32 +77,48 @@ inline PlanInfo make_plan(const bfsm_desc& d) {
     const long long B = (long long)d.n_gl * d.n_sph;
     if (d.dir_begin == 0 && d.dir_end == 0) { p.dir_begin = 0; p.dir_end = B; }
     else { p.dir_begin = d.dir_begin; p.dir_end = d.dir_end; }
-    p.max_chunk = d.max_chunk > 0 ? d.max_chunk : 64;
+    // Directions resident at once.  Sized for 288 GB of HBM: by default the whole shard (up to 1024 directions,
+    // i.e. 8 GiB of A1'/A2' scratch at N=64 fp64) is one chunk, so an evaluation is ~8 launches.
+    p.max_chunk = d.max_chunk > 0 ? d.max_chunk : 1024;
     p.groups = (512 + p.N - 1) / p.N;           // >= 2 workgroups per CU on 256 CUs
-    if (p.groups > p.max_chunk) p.groups = p.max_chunk;
     if (p.groups < 1) p.groups = 1;
     p.n2stride = 3 * (p.N / 2) * (p.N / 2) + 1;
-    int slab = 0;
-    long long b = p.dir_begin;
-    while (b < p.dir_end) {
-        const int r = (int)(b / d.n_sph);
-        long long r_end = (long long)(r + 1) * d.n_sph;
-        if (r_end > p.dir_end) r_end = p.dir_end;
-        const long long len = r_end - b;
+    const long long len = p.dir_end - p.dir_begin;
+    if (len > 0) {
         const long long pieces = (len + p.max_chunk - 1) / p.max_chunk;
         const long long piece = (len + pieces - 1) / pieces;
         for (long long o = 0; o < len; o += piece) {
             Chunk c;
-            c.r = r;
-            c.dir0 = (b + o) - p.dir_begin;
+            c.dir0 = o;
             c.n = (int)((o + piece <= len) ? piece : (len - o));
             c.per_group = (c.n + p.groups - 1) / p.groups;
-            c.slab0 = slab;
-            slab += p.groups;
+            c.seg0 = (int)p.segs.size();
+            // radial runs inside the chunk; every run is cut into `cuts` near-equal segments so that the chunk
+            // offers at least `groups` accumulating workgroups per x-plane
+            const long long g0 = p.dir_begin + o, g1 = g0 + c.n;
+            const int r_first = (int)(g0 / d.n_sph), r_last = (int)((g1 - 1) / d.n_sph);
+            const int runs = r_last - r_first + 1;
+            const int cuts = (p.groups + runs - 1) / runs;
+            for (int r = r_first; r <= r_last; ++r) {
+                long long a0 = (long long)r * d.n_sph, a1 = a0 + d.n_sph;
+                if (a0 < g0) a0 = g0;
+                if (a1 > g1) a1 = g1;
+                const long long rl = a1 - a0;
+                const long long k = rl < cuts ? rl : cuts;
+                for (long long j = 0; j < k; ++j) {
+                    const long long s0 = a0 + rl * j / k, s1 = a0 + rl * (j + 1) / k;
+                    Segment sg;
+                    sg.d0 = (int)(s0 - g0);
+                    sg.n = (int)(s1 - s0);
+                    sg.r = r;
+                    sg.pad = 0;
+                    p.segs.push_back(sg);
+                }
+            }
+            c.n_seg = (int)p.segs.size() - c.seg0;
             if (c.n > p.largest_chunk) p.largest_chunk = c.n;
             p.chunks.push_back(c);
         }
-        b = r_end;
     }
     return p;
 }
@@ -114,7 +131,6 @@ struct HostTables {
     std::vector<T> dirw;                   // [n_dirs]
     std::vector<T> beta1;                  // [n_gl][n2stride]
     std::vector<T> beta2;                  // [n2stride]
-    std::vector<int> chunk_r;              // [n_chunks]
 };
 
 template <typename T>
@@ -166,8 +182,6 @@ HostTables<T> build_tables(const bfsm_desc& d, const PlanInfo& p) {
         }
         t.beta2[n2] = (T)(fft_scale * b2[n2]);   // cpp:295-296 folds fft_scale
     }
-    t.chunk_r.resize(p.chunks.size());
-    for (size_t c = 0; c < p.chunks.size(); ++c) t.chunk_r[c] = p.chunks[c].r;
     return t;
 }
 
@@ -197,7 +211,7 @@ struct Pipeline {
     T* dirw = nullptr;
     T* beta1 = nullptr;
     T* beta2 = nullptr;
-    int* chunk_r = nullptr;
+    Segment* segs = nullptr;
     size_t slab_count = 0;
 
     template <typename U>
@@ -215,7 +229,7 @@ struct Pipeline {
         HostTables<T> t = build_tables<T>(d, plan);
         const size_t G = plan.G();
         const size_t cap = (size_t)(plan.largest_chunk > 0 ? plan.largest_chunk : 1);
-        slab_count = plan.chunks.size() * (size_t)plan.groups;
+        slab_count = plan.segs.size();
         bool ok = true;
         ok = ok && (fhat = (cx<T>*)be->alloc(G * sizeof(cx<T>)));
         ok = ok && (tg = (cx<T>*)be->alloc(G * sizeof(cx<T>)));
@@ -225,18 +239,18 @@ struct Pipeline {
         ok = ok && (a2 = (cx<T>*)be->alloc(cap * G * sizeof(cx<T>)));
         ok = ok && (slab = (cx<T>*)be->alloc((slab_count ? slab_count : 1) * G * sizeof(cx<T>)));
         ok = ok && dev_copy(tw, t.tw) && dev_copy(phx, t.phx) && dev_copy(phy, t.phy) && dev_copy(phz, t.phz);
-        ok = ok && dev_copy(dirw, t.dirw) && dev_copy(beta1, t.beta1) && dev_copy(beta2, t.beta2) && dev_copy(chunk_r, t.chunk_r);
+        ok = ok && dev_copy(dirw, t.dirw) && dev_copy(beta1, t.beta1) && dev_copy(beta2, t.beta2) && dev_copy(segs, plan.segs);
         if (!ok) { err = "device allocation failed"; return BFSM_ERR_NOMEM; }
         return BFSM_OK;
     }
 
     void destroy() {
         if (!be) return;
-        void* ptrs[] = {fhat, tg, tl, qhat, a1, a2, slab, tw, phx, phy, phz, dirw, beta1, beta2, chunk_r};
+        void* ptrs[] = {fhat, tg, tl, qhat, a1, a2, slab, tw, phx, phy, phz, dirw, beta1, beta2, segs};
         for (void* p : ptrs) if (p) be->release(p);
         fhat = tg = tl = qhat = a1 = a2 = slab = tw = phx = phy = phz = nullptr;
         dirw = beta1 = beta2 = nullptr;
-        chunk_r = nullptr;
+        segs = nullptr;
     }
 
     double cbytes() const { return (double)sizeof(cx<T>); }
@@ -261,11 +275,11 @@ struct Pipeline {
             GainLineParams<T> kb{a1, a2, tw};
             be->mark(BFSM_K_GAIN_LINE, 3.0 * c.n * Gc);
             be->template launch<K::GainLine, T>(N, c.n, kb, N);
-            GainFwdParams<T> kc{a1, slab, dirw, tw, c.dir0, c.n, c.per_group, c.slab0};
+            GainFwdParams<T> kc{a1, slab, dirw, segs, tw, c.dir0, c.seg0};
             be->mark(BFSM_K_GAIN_FWD, 1.0 * c.n * Gc);
-            be->template launch<K::GainFwd, T>(N, plan.groups, kc, N);
+            be->template launch<K::GainFwd, T>(N, c.n_seg, kc, N);
         }
-        ReduceParams<T> kr{slab, qhat, beta1, chunk_r, (int)plan.chunks.size(), plan.groups, plan.n2stride};
+        ReduceParams<T> kr{slab, qhat, beta1, segs, (int)slab_count, plan.n2stride};
         be->mark(BFSM_K_REDUCE, ((double)slab_count + 1.0) * Gc);
         be->template launch<K::Reduce, T>((int)((plan.G() + 255) / 256), 1, kr, N);
     }

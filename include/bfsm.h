@@ -70,7 +70,8 @@ typedef struct bfsm_desc {
     int device;               /* HIP device ordinal                       */
     long long dir_begin;      /* shard of the flattened quadrature directions b = r*n_sph + s handled by this   */
     long long dir_end;        /* handle: [dir_begin, dir_end).  0,0 = all directions (single-GPU behaviour).     */
-    int max_chunk;            /* directions resident at once (0 = default 64); bounds scratch, not results       */
+    int max_chunk;            /* directions resident at once (0 = default 1024: the whole shard in one pass when it
+                                 fits; scratch = 2 * chunk * G complex); bounds scratch, not results                 */
     int flags;                /* BFSM_FLAG_*                              */
 } bfsm_desc;
 

@@ -187,16 +187,24 @@ int bfsm_emu_fft3d(int N, int precision, double* data, int batch, int sign) {
     return emu::fft3d_t<float>(N, data, batch, sign);
 }
 
-// Plan introspection for the host-logic tests: fills chunk (r, dir0, n, per_group, slab0) rows, returns the count.
-int bfsm_emu_plan(const bfsm_desc* d, int* rows, int max_rows, int* groups) {
+// Plan introspection for the host-logic tests.  Chunk rows: (n_seg, dir0, n, per_group, seg0).  Segment rows:
+// (chunk, d0 relative to the chunk, n, r, 0).  Returns the chunk count; *n_segs receives the segment count.
+int bfsm_emu_plan(const bfsm_desc* d, int* chunk_rows, int max_chunks, int* seg_rows, int max_segs, int* n_segs) {
     std::string err;
     int rc = bfsm::validate_desc(*d, err);
     if (rc) return -rc;
     bfsm::PlanInfo p = bfsm::make_plan(*d);
-    if (groups) *groups = p.groups;
+    if (n_segs) *n_segs = (int)p.segs.size();
     int n = 0;
     for (const auto& c : p.chunks) {
-        if (n < max_rows) { rows[5 * n] = c.r; rows[5 * n + 1] = (int)c.dir0; rows[5 * n + 2] = c.n; rows[5 * n + 3] = c.per_group; rows[5 * n + 4] = c.slab0; }
+        if (n < max_chunks) {
+            int* r = chunk_rows + 5 * n;
+            r[0] = c.n_seg; r[1] = (int)c.dir0; r[2] = c.n; r[3] = c.per_group; r[4] = c.seg0;
+        }
+        for (int i = c.seg0; i < c.seg0 + c.n_seg && i < max_segs; ++i) {
+            int* r = seg_rows + 5 * i;
+            r[0] = n; r[1] = p.segs[i].d0; r[2] = p.segs[i].n; r[3] = p.segs[i].r; r[4] = 0;
+        }
         ++n;
     }
     return n;

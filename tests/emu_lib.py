@@ -20,8 +20,8 @@ def lib():
         L.bfsm_emu_collide.restype = ctypes.c_int
         L.bfsm_emu_fft3d.argtypes = [ctypes.c_int, ctypes.c_int, dp, ctypes.c_int, ctypes.c_int]
         L.bfsm_emu_fft3d.restype = ctypes.c_int
-        L.bfsm_emu_plan.argtypes = [ctypes.POINTER(capi.Desc), ctypes.POINTER(ctypes.c_int), ctypes.c_int,
-                                    ctypes.POINTER(ctypes.c_int)]
+        ip = ctypes.POINTER(ctypes.c_int)
+        L.bfsm_emu_plan.argtypes = [ctypes.POINTER(capi.Desc), ip, ctypes.c_int, ip, ctypes.c_int, ip]
         L.bfsm_emu_plan.restype = ctypes.c_int
         _LIB = L
     return _LIB
@@ -69,12 +69,15 @@ def fft3d(a, sign, precision=64):
 
 
 def plan(nv, n_gl, n_sph, precision=64, dir_range=(0, 0), max_chunk=0):
+    """Returns (chunks, segments): chunk rows (n_seg, dir0, n, per_group, seg0), segment rows (chunk, d0, n, r)."""
     gl = (np.ones(n_gl), np.ones(n_gl))
     sph = (np.ones(n_sph), np.zeros(n_sph), np.zeros(n_sph), np.ones(n_sph))
     d, keep = make_desc(nv, gl, sph, 0.0, 1.0, 1.0, precision, dir_range, max_chunk)
-    rows = (ctypes.c_int * (5 * 4096))()
-    groups = ctypes.c_int()
-    n = lib().bfsm_emu_plan(ctypes.byref(d), rows, 4096, ctypes.byref(groups))
+    crow = (ctypes.c_int * (5 * 4096))()
+    srow = (ctypes.c_int * (5 * 65536))()
+    nseg = ctypes.c_int()
+    n = lib().bfsm_emu_plan(ctypes.byref(d), crow, 4096, srow, 65536, ctypes.byref(nseg))
     if n < 0:
         raise ValueError(f"plan rejected rc={-n}")
-    return [tuple(rows[5 * i:5 * i + 5]) for i in range(n)], groups.value
+    return ([tuple(crow[5 * i:5 * i + 5]) for i in range(n)],
+            [tuple(srow[5 * i:5 * i + 4]) for i in range(nseg.value)])

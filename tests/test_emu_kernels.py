@@ -77,21 +77,33 @@ def test_empty_shard_gives_zero_gain(oracle):
     assert np.all(qh == 0)
 
 
-def test_plan_chunks_cover_shard_once():
-    """Host logic: chunks never straddle a radial node, respect max_chunk, tile the shard exactly."""
+def test_plan_chunks_and_segments_cover_shard_once():
+    """Host logic: chunks respect max_chunk (default: whole shard up to 1024 directions) and tile the shard; the
+    accumulation segments tile every chunk, never straddle a radial node (beta1 is applied per slab), and give
+    every x-plane at least 8 workgroups when the chunk has that many directions."""
     for nv, n_gl, n_sph, rng_, mc in [(64, 16, 48, (0, 0), 0), (64, 16, 156, (0, 0), 0), (128, 30, 192, (0, 0), 0),
-                                      (64, 16, 156, (312, 624), 0), (16, 3, 12, (7, 20), 5), (32, 8, 48, (0, 0), 7)]:
+                                      (64, 16, 156, (312, 624), 0), (16, 3, 12, (7, 20), 5), (32, 8, 48, (0, 0), 7),
+                                      (64, 2, 12, (0, 0), 0), (64, 1, 6, (0, 0), 0), (64, 16, 48, (100, 101), 0)]:
         prec = 32 if nv == 128 else 64
-        chunks, groups = E.plan(nv, n_gl, n_sph, prec, rng_, mc)
+        chunks, segs = E.plan(nv, n_gl, n_sph, prec, rng_, mc)
         b0, b1 = rng_ if rng_ != (0, 0) else (0, n_gl * n_sph)
-        cap = mc or 64
-        pos = 0
-        for i, (r, d0, n, per_group, slab0) in enumerate(chunks):
-            assert d0 == pos and 1 <= n <= cap
-            assert (b0 + d0) // n_sph == r == (b0 + d0 + n - 1) // n_sph
-            assert per_group * groups >= n and slab0 == i * groups
+        cap = mc or 1024
+        assert len(chunks) == -(-(b1 - b0) // cap)
+        pos, seg_pos = 0, 0
+        for ci, (n_seg, d0, n, per_group, seg0) in enumerate(chunks):
+            assert d0 == pos and 1 <= n <= cap and seg0 == seg_pos
+            assert per_group * ((512 + nv - 1) // nv) >= n
+            inner = 0
+            for (c, sd0, sn, r) in segs[seg0:seg0 + n_seg]:
+                assert c == ci and sd0 == inner and sn >= 1
+                g_first, g_last = b0 + d0 + sd0, b0 + d0 + sd0 + sn - 1
+                assert g_first // n_sph == r == g_last // n_sph
+                inner += sn
+            assert inner == n
+            assert n_seg >= min(n, (512 + nv - 1) // nv)
             pos += n
-        assert pos == b1 - b0
+            seg_pos += n_seg
+        assert pos == b1 - b0 and seg_pos == len(segs)
 
 
 def test_plan_rejects_unsupported():
