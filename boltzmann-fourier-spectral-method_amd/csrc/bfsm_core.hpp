@@ -130,13 +130,21 @@ struct Wg {
 // ---- one distributed 1-D transform -------------------------------------------------------------------------
 // v[m] = x[u + T*m] on entry, X[u + T*m] on exit.  lds rows are indexed by position along the line, columns
 // by the lane index p.  tw[n] = exp(-2*pi*i*n/N) (forward table; conjugated for SGN = +1).
+// twr[k1-1] = tw[u*k1] are this thread's E-1 inter-step twiddles, loaded once per kernel by load_twiddles()
+// (wave-uniform for N >= 64, so they live in SGPRs and cost no vector-memory latency inside the direction loops).
+template <int N, typename T, class Ctx>
+BFSM_HD void load_twiddles(cx<T>* twr, const cx<T>* tw, int u, Ctx& ctx) {
+#pragma unroll
+    for (int k1 = 1; k1 < Wg<N>::E; ++k1) twr[k1 - 1] = ctx.ldc(tw + u * k1);
+}
+
 template <int N, int SGN, typename T, class Ctx>
-BFSM_HD void fft_line(cx<T>* v, cx<T>* lds, int p, int u, const cx<T>* __restrict__ tw, Ctx& ctx) {
+BFSM_HD void fft_line(cx<T>* v, cx<T>* lds, int p, int u, const cx<T>* twr, Ctx& ctx) {
     constexpr int E = Wg<N>::E, TT = Wg<N>::T, Q = Wg<N>::Q, LS = Wg<N>::LS;
     SmallDft<E, SGN, T>::run(v);
 #pragma unroll
     for (int k1 = 1; k1 < E; ++k1) {
-        const cx<T> w = tw[u * k1];
+        const cx<T> w = twr[k1 - 1];
         v[k1] = (SGN < 0) ? cmul(v[k1], w) : cmulc(v[k1], w);
     }
     ctx.sync();  // previous readers of lds are done
@@ -161,16 +169,16 @@ BFSM_HD void fft_line(cx<T>* v, cx<T>* lds, int p, int u, const cx<T>* __restric
 // entry: v[m] = tile[a = u + T*m][c = p]      (c is the contiguous axis of the source)
 // exit : v[m] = TILE[a' = p][c' = u + T*m]    (to be stored as out[c'][a'], a' contiguous)
 template <int N, int SGN, typename T, class Ctx>
-BFSM_HD void fft_tile(cx<T>* v, cx<T>* lds, int p, int u, const cx<T>* __restrict__ tw, Ctx& ctx) {
+BFSM_HD void fft_tile(cx<T>* v, cx<T>* lds, int p, int u, const cx<T>* twr, Ctx& ctx) {
     constexpr int E = Wg<N>::E, TT = Wg<N>::T, LS = Wg<N>::LS;
-    fft_line<N, SGN, T>(v, lds, p, u, tw, ctx);  // along a
+    fft_line<N, SGN, T>(v, lds, p, u, twr, ctx);  // along a
     ctx.sync();
 #pragma unroll
     for (int m = 0; m < E; ++m) lds[(u + TT * m) * LS + p] = v[m];  // row a', column c
     ctx.sync();
 #pragma unroll
     for (int m = 0; m < E; ++m) v[m] = lds[p * LS + (u + TT * m)];  // lane = a', own c = u + T*m
-    fft_line<N, SGN, T>(v, lds, p, u, tw, ctx);  // along c
+    fft_line<N, SGN, T>(v, lds, p, u, twr, ctx);  // along c
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -274,11 +282,13 @@ BFSM_HD void body_tile_fwd_real(const TileFwdRealParams<T>& prm, Ctx& ctx) {
     const int tid = ctx.tid(), p = tid % N, u = ctx.uniform(tid / N, N);
     const int x = ctx.bx();
     cx<T>* lds = ctx.template lds<cx<T>>();
+    cx<T> twr[E - 1];
+    load_twiddles<N, T>(twr, prm.tw, u, ctx);
     cx<T> v[E];
     const double* src = prm.f + (size_t)x * N * N;
 #pragma unroll
     for (int m = 0; m < E; ++m) v[m] = {(T)src[(u + TT * m) * N + p], (T)0};
-    fft_tile<N, -1, T>(v, lds, p, u, prm.tw, ctx);
+    fft_tile<N, -1, T>(v, lds, p, u, twr, ctx);
     cx<T>* dst = prm.out + (size_t)x * N * N;
 #pragma unroll
     for (int m = 0; m < E; ++m) dst[(u + TT * m) * N + p] = v[m];
@@ -292,10 +302,12 @@ BFSM_HD void body_tile_c2c(const LineParams<T>& prm, Ctx& ctx) {
     const int tid = ctx.tid(), p = tid % N, u = ctx.uniform(tid / N, N);
     const size_t base = ((size_t)ctx.by() * N + ctx.bx()) * N * N;
     cx<T>* lds = ctx.template lds<cx<T>>();
+    cx<T> twr[E - 1];
+    load_twiddles<N, T>(twr, prm.tw, u, ctx);
     cx<T> v[E];
 #pragma unroll
     for (int m = 0; m < E; ++m) v[m] = prm.in[base + (u + TT * m) * N + p];
-    fft_tile<N, SGN, T>(v, lds, p, u, prm.tw, ctx);
+    fft_tile<N, SGN, T>(v, lds, p, u, twr, ctx);
     ctx.sync();  // in place: every thread of the plane has loaded before anyone stores (loads precede the syncs above)
 #pragma unroll
     for (int m = 0; m < E; ++m) prm.out[base + (u + TT * m) * N + p] = v[m];
@@ -308,10 +320,12 @@ BFSM_HD void body_line(const LineParams<T>& prm, Ctx& ctx) {
     const int tid = ctx.tid(), p = tid % N, u = ctx.uniform(tid / N, N);
     const size_t base = (size_t)ctx.by() * N * N * N + (size_t)ctx.bx() * N + p;
     cx<T>* lds = ctx.template lds<cx<T>>();
+    cx<T> twr[E - 1];
+    load_twiddles<N, T>(twr, prm.tw, u, ctx);
     cx<T> v[E];
 #pragma unroll
     for (int m = 0; m < E; ++m) v[m] = prm.in[base + (size_t)(u + TT * m) * N * N];
-    fft_line<N, SGN, T>(v, lds, p, u, prm.tw, ctx);
+    fft_line<N, SGN, T>(v, lds, p, u, twr, ctx);
 #pragma unroll
     for (int m = 0; m < E; ++m) prm.out[base + (size_t)(u + TT * m) * N * N] = v[m];
 }
@@ -325,6 +339,8 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
     const int tid = ctx.tid(), p = tid % N, u = ctx.uniform(tid / N, N);
     const int lxi = ctx.bx();
     cx<T>* lds = ctx.template lds<cx<T>>();
+    cx<T> twr[E - 1];
+    load_twiddles<N, T>(twr, prm.tw, u, ctx);
     cx<T> fh[E];
     const cx<T>* src = prm.fhat + (size_t)lxi * N * N;
 #pragma unroll
@@ -332,24 +348,29 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
     const int d_begin = ctx.by() * prm.per_group;
     int d_end = d_begin + prm.per_group;
     if (d_end > prm.n_dir) d_end = prm.n_dir;
-    for (int d = d_begin; d < d_end; ++d) {
+    // One iteration = one signed direction (j = 2*d + sign).  Phase of this thread's points:
+    // e^{+-i theta} / G = (phx[lx] * phy[ly = p]) * phz[lz = u + T m], conjugated for sign 1.  The phz / phx factors
+    // are wave-uniform scalar loads; the per-lane phy factor of the NEXT iteration is fetched before this
+    // iteration's transform so that its latency hides behind the butterflies.
+    const int j_end = 2 * d_end;
+    cx<T> py = {(T)0, (T)0};
+    if (d_begin < d_end) py = prm.phy[(size_t)(prm.dir0 + d_begin) * N + p];
+    for (int j = 2 * d_begin; j < j_end; ++j) {
+        const int d = j >> 1;
+        const bool conj = (j & 1) != 0;
         const size_t b = (size_t)(prm.dir0 + d);
-        // phase of this thread's points: e^{i theta} / G = phx[lx] * phy[ly = p] * phz[lz = u + T m]; the phz
-        // factors are wave-uniform (scalar loads), so they are re-read per sign instead of held in registers
-        const cx<T> c0 = cmul(prm.phx[b * N + lxi], prm.phy[b * N + p]);
-        const cx<T>* __restrict__ pz = prm.phz + b * N + u;
-        const size_t obase = ((size_t)d * N + lxi) * N * N;
+        const cx<T> c0 = cmul(ctx.ldc(prm.phx + b * N + lxi), py);
+        if (j + 1 < j_end) py = prm.phy[(size_t)(prm.dir0 + ((j + 1) >> 1)) * N + p];
         cx<T> v[E];
 #pragma unroll
-        for (int m = 0; m < E; ++m) v[m] = cmul(fh[m], cmul(c0, pz[TT * m]));    // alpha1 * f_hat / G
-        fft_tile<N, +1, T>(v, lds, p, u, prm.tw, ctx);
+        for (int m = 0; m < E; ++m) {
+            const cx<T> ph = cmul(c0, ctx.ldc(prm.phz + b * N + u + TT * m));
+            v[m] = conj ? cmulc(fh[m], ph) : cmul(fh[m], ph);   // conj(alpha1) f_hat / G  :  alpha1 f_hat / G
+        }
+        fft_tile<N, +1, T>(v, lds, p, u, twr, ctx);
+        cx<T>* dst = (conj ? prm.a2 : prm.a1) + ((size_t)d * N + lxi) * N * N;
 #pragma unroll
-        for (int m = 0; m < E; ++m) prm.a1[obase + (size_t)(u + TT * m) * N + p] = v[m];  // [y][z = p]
-#pragma unroll
-        for (int m = 0; m < E; ++m) v[m] = cmulc(fh[m], cmul(c0, pz[TT * m]));   // conj(alpha1) * f_hat / G
-        fft_tile<N, +1, T>(v, lds, p, u, prm.tw, ctx);
-#pragma unroll
-        for (int m = 0; m < E; ++m) prm.a2[obase + (size_t)(u + TT * m) * N + p] = v[m];
+        for (int m = 0; m < E; ++m) dst[(size_t)(u + TT * m) * N + p] = v[m];  // [y = u + T m][z = p]
     }
 }
 
@@ -361,16 +382,18 @@ BFSM_HD void body_gain_line(const GainLineParams<T>& prm, Ctx& ctx) {
     const int tid = ctx.tid(), p = tid % N, u = ctx.uniform(tid / N, N);
     const size_t base = (size_t)ctx.by() * N * N * N + (size_t)ctx.bx() * N + p;
     cx<T>* lds = ctx.template lds<cx<T>>();
+    cx<T> twr[E - 1];
+    load_twiddles<N, T>(twr, prm.tw, u, ctx);
     cx<T> a[E], b[E];
 #pragma unroll
     for (int m = 0; m < E; ++m) a[m] = prm.a1[base + (size_t)(u + TT * m) * N * N];
 #pragma unroll
     for (int m = 0; m < E; ++m) b[m] = prm.a2[base + (size_t)(u + TT * m) * N * N];
-    fft_line<N, +1, T>(a, lds, p, u, prm.tw, ctx);
-    fft_line<N, +1, T>(b, lds, p, u, prm.tw, ctx);
+    fft_line<N, +1, T>(a, lds, p, u, twr, ctx);
+    fft_line<N, +1, T>(b, lds, p, u, twr, ctx);
 #pragma unroll
     for (int m = 0; m < E; ++m) a[m] = cmul(a[m], b[m]);
-    fft_line<N, -1, T>(a, lds, p, u, prm.tw, ctx);
+    fft_line<N, -1, T>(a, lds, p, u, twr, ctx);
 #pragma unroll
     for (int m = 0; m < E; ++m) prm.a1[base + (size_t)(u + TT * m) * N * N] = a[m];
 }
@@ -384,6 +407,8 @@ BFSM_HD void body_gain_fwd(const GainFwdParams<T>& prm, Ctx& ctx) {
     const int tid = ctx.tid(), p = tid % N, u = ctx.uniform(tid / N, N);
     const int x = ctx.bx();
     cx<T>* lds = ctx.template lds<cx<T>>();
+    cx<T> twr[E - 1];
+    load_twiddles<N, T>(twr, prm.tw, u, ctx);
     cx<T> acc[E];
 #pragma unroll
     for (int m = 0; m < E; ++m) acc[m] = {(T)0, (T)0};
@@ -393,7 +418,7 @@ BFSM_HD void body_gain_fwd(const GainFwdParams<T>& prm, Ctx& ctx) {
         cx<T> v[E];
 #pragma unroll
         for (int m = 0; m < E; ++m) v[m] = src[(u + TT * m) * N + p];  // [y = u + T m][z = p]
-        fft_tile<N, -1, T>(v, lds, p, u, prm.tw, ctx);
+        fft_tile<N, -1, T>(v, lds, p, u, twr, ctx);
         const T w = prm.dirw[prm.dir0 + d];
 #pragma unroll
         for (int m = 0; m < E; ++m) {
@@ -436,6 +461,8 @@ BFSM_HD void body_tail_inv(const TailInvParams<T>& prm, Ctx& ctx) {
     const int lxi = ctx.bx();
     const bool loss = ctx.by() != 0;
     cx<T>* lds = ctx.template lds<cx<T>>();
+    cx<T> twr[E - 1];
+    load_twiddles<N, T>(twr, prm.tw, u, ctx);
     cx<T> v[E];
     const size_t pbase = (size_t)lxi * N * N;
     if (!loss) {
@@ -451,7 +478,7 @@ BFSM_HD void body_tail_inv(const TailInvParams<T>& prm, Ctx& ctx) {
             v[m] = {b2 * t.x, b2 * t.y};
         }
     }
-    fft_tile<N, +1, T>(v, lds, p, u, prm.tw, ctx);
+    fft_tile<N, +1, T>(v, lds, p, u, twr, ctx);
     cx<T>* dst = (loss ? prm.tl : prm.tg) + pbase;
 #pragma unroll
     for (int m = 0; m < E; ++m) dst[(u + TT * m) * N + p] = v[m];
@@ -465,13 +492,15 @@ BFSM_HD void body_tail_line(const TailLineParams<T>& prm, Ctx& ctx) {
     const int tid = ctx.tid(), p = tid % N, u = ctx.uniform(tid / N, N);
     const size_t base = (size_t)ctx.bx() * N + p;
     cx<T>* lds = ctx.template lds<cx<T>>();
+    cx<T> twr[E - 1];
+    load_twiddles<N, T>(twr, prm.tw, u, ctx);
     cx<T> g[E], l[E];
 #pragma unroll
     for (int m = 0; m < E; ++m) g[m] = prm.tg[base + (size_t)(u + TT * m) * N * N];
 #pragma unroll
     for (int m = 0; m < E; ++m) l[m] = prm.tl[base + (size_t)(u + TT * m) * N * N];
-    fft_line<N, +1, T>(g, lds, p, u, prm.tw, ctx);
-    fft_line<N, +1, T>(l, lds, p, u, prm.tw, ctx);
+    fft_line<N, +1, T>(g, lds, p, u, twr, ctx);
+    fft_line<N, +1, T>(l, lds, p, u, twr, ctx);
 #pragma unroll
     for (int m = 0; m < E; ++m) {
         const size_t i = base + (size_t)(u + TT * m) * N * N;

@@ -26,6 +26,17 @@ struct DevCtx {
     }
     template <class U>
     __device__ __forceinline__ U* lds() const { return reinterpret_cast<U*>(smem); }
+    // read-only table element through the constant address space: with a wave-uniform address the compiler
+    // emits s_load (scalar data cache, SGPR result) even when the kernel also stores to global memory
+    template <class T>
+    __device__ __forceinline__ cx<T> ldc(const cx<T>* p) const {
+        typedef const T __attribute__((address_space(4))) * cptr;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+        cptr q = (cptr)(reinterpret_cast<const T*>(p));
+#pragma clang diagnostic pop
+        return cx<T>{q[0], q[1]};
+    }
 };
 
 template <K kind, int N>

@@ -28,6 +28,7 @@ struct EmuCtx {
     int by() const { return by_; }
     int uniform(int v, int) const { return v; }
     template <class U> U* lds() const { return reinterpret_cast<U*>(smem); }
+    template <class U> U ldc(const U* p) const { return *p; }
     void sync();
 };
 
