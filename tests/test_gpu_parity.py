@@ -221,3 +221,24 @@ def test_fp32_config5_shape_runs_and_matches_fp64_on_a_subset(torch_cuda):
     assert np.isfinite(got).all()
     q2 = _sharded_collide(torch, bfsm, nv, n_gl, n_sph, f, 2, precision=32)
     assert np.abs(q2 - got).max() <= 1e-4 * np.abs(got).max()
+
+
+def test_cpp_driver_reproduces_published_norms(torch_cuda):
+    """The C++ mirror of the reference's operator class + BKW driver (host/maxwell_bkw_hip.cpp), run like the
+    reference's `maxwell_bkw_cuda_ex --Nv 32 --Ns 12`, prints the norms archived in
+    Results/maxwell_bkw_fftw_atomics.txt:19-21."""
+    import re
+    import subprocess
+    exe = os.path.join(os.path.dirname(HERE), "boltzmann-fourier-spectral-method_amd", "maxwell_bkw_hip")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.dirname(exe), "-s", "maxwell_bkw_hip"])
+    out = subprocess.run([exe, "--Nv", "32", "--Ns", "12", "-t", "3", "--design-dir",
+                          os.path.join(os.path.dirname(exe), "data", "sph_design")],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    text = out.stdout
+    assert "Run statistics for HIP" in text and "Total number of samples taken: 3" in text
+    got = {k: float(re.search(k + r" error: (\S+)", text).group(1)) for k in ("L1", "L2", "Linf")}
+    row = GOLD["published"][0]
+    for k in ("L1", "L2", "Linf"):
+        assert got[k] == pytest.approx(row[k], rel=2e-5), (k, got, text)     # std::cout prints 6 significant digits
