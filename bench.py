@@ -37,15 +37,6 @@ WORKLOADS = {
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling there: 6290 GB/s
 
 
-def _dev_view(torch, ptr, n, prec):
-    class V:
-        pass
-    v = V()
-    v.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8" if prec == 64 else "<f4",
-                                  "data": (int(ptr), False), "version": 2}
-    return torch.as_tensor(v, device="cuda")
-
-
 def cpu_baseline(w, seconds_target=15.0):
     """The oracle (CPU restatement of the reference's FFTW path, kind "port") timed on this box's host cores on a
     bounded sample: the first n_sample directions of the same workload, all OpenMP threads."""
@@ -130,16 +121,14 @@ def main():
     op = make(False)
     f = torch.from_numpy(f_h).cuda()
     Q = torch.empty_like(f)
-    qhat = _dev_view(torch, *op.qhatBuffer()) if world > 1 else None
+    qhat = bfsm.device_view(torch, *op.qhatBuffer()) if world > 1 else None
 
     def step():
         s = torch.cuda.current_stream().cuda_stream
         if world == 1:
             op.computeCollisionAsync(Q, f, s)
         else:
-            op.gainPartial(f, s)
-            dist.all_reduce(qhat)                 # the single RCCL collective of an evaluation
-            op.finish(Q, f, s)
+            bfsm.sharded_step(op, qhat, Q, f, dist, s)   # gain_partial -> ONE RCCL all-reduce -> finish
 
     def fence():
         torch.cuda.synchronize()

@@ -1,0 +1,24 @@
+"""Sharded (multi-GPU) evaluation: quadrature directions split contiguously over ranks, ONE sum all-reduce of the
+partial Q_gain_hat per evaluation (RCCL over xGMI when the process group is "nccl"), tail replicated on every rank.
+
+`op` is anything with gainPartial(f, stream) / finish(Q, f, stream) -- the HIP operator on a GPU box, or the
+host-emulated operator in the world-size-2 gloo tests.  `qhat` is a tensor view of the operator's partial-sum buffer.
+"""
+
+
+def sharded_step(op, qhat, Q, f, dist=None, stream=0):
+    """One collision evaluation on this rank's shard.  With dist=None it degenerates to the single-device path."""
+    op.gainPartial(f, stream)
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(qhat)            # the single collective of an evaluation (sum)
+    op.finish(Q, f, stream)
+
+
+def device_view(torch, ptr, n, precision):
+    """Zero-copy torch tensor over a raw device pointer (the handle-owned Q_gain_hat buffer)."""
+    class _View:
+        pass
+    v = _View()
+    v.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8" if precision == 64 else "<f4",
+                                  "data": (int(ptr), False), "version": 2}
+    return torch.as_tensor(v, device="cuda")

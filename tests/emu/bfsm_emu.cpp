@@ -146,6 +146,25 @@ int collide_t(const bfsm_desc* d, const double* f, double* Q, double* qhat_out) 
     return 0;
 }
 
+// Tail only: f_hat is recomputed (gain of an empty shard), qhat_in replaces the handle's buffer (what the all-reduce
+// leaves there on a multi-GPU node), then bfsm_finish.
+template <typename T>
+int finish_t(const bfsm_desc* d, const double* f, const double* qhat_in, double* Q) {
+    EmuBackend be;
+    bfsm::Pipeline<T, EmuBackend> p;
+    std::string err;
+    bfsm_desc e = *d;
+    e.dir_begin = e.dir_end = 1;   // empty shard: F1 + zero gain
+    int rc = p.init(e, &be, err);
+    if (rc) return rc;
+    p.gain_partial(f);
+    const size_t G = p.plan.G();
+    for (size_t i = 0; i < G; ++i) p.qhat[i] = {(T)qhat_in[2 * i], (T)qhat_in[2 * i + 1]};
+    p.finish(Q, f);
+    p.destroy();
+    return 0;
+}
+
 template <typename T>
 int fft3d_t(int N, double* data, int batch, int sign) {
     EmuBackend be;
@@ -179,6 +198,14 @@ int bfsm_emu_collide(const bfsm_desc* d, const double* f, double* Q, double* qha
     int rc = bfsm::validate_desc(*d, err);
     if (rc) return rc;
     return d->precision == BFSM_F64 ? emu::collide_t<double>(d, f, Q, qhat_out) : emu::collide_t<float>(d, f, Q, qhat_out);
+}
+
+// Emulated bfsm_finish on a caller-provided (already reduced) Q_gain_hat in the spectral layout.
+int bfsm_emu_finish(const bfsm_desc* d, const double* f, const double* qhat_in, double* Q) {
+    std::string err;
+    int rc = bfsm::validate_desc(*d, err);
+    if (rc) return rc;
+    return d->precision == BFSM_F64 ? emu::finish_t<double>(d, f, qhat_in, Q) : emu::finish_t<float>(d, f, qhat_in, Q);
 }
 
 // Emulated bfsm_fft3d; data = batch*G interleaved complex doubles (narrowed to float when precision == 32).

@@ -81,3 +81,44 @@ def plan(nv, n_gl, n_sph, precision=64, dir_range=(0, 0), max_chunk=0):
         raise ValueError(f"plan rejected rc={-n}")
     return ([tuple(crow[5 * i:5 * i + 5]) for i in range(n)],
             [tuple(srow[5 * i:5 * i + 4]) for i in range(nseg.value)])
+
+
+class EmuOperator:
+    """Host-emulated stand-in for bfsm.HIPBoltzmannOperator with the sharded interface (gainPartial / qhat / finish),
+    used by the world-size-2 gloo tests of the multi-GPU logic.  CPU torch tensors instead of device tensors."""
+
+    def __init__(self, nv, gl, sph, gamma, b_gamma, L, dir_range=(0, 0), max_chunk=0):
+        import torch
+        self.nv, self.gl, self.sph = nv, gl, sph
+        self.args = (gamma, b_gamma, L)
+        self.dir_range, self.max_chunk = dir_range, max_chunk
+        self.qhat = torch.zeros(2 * nv ** 3, dtype=torch.float64)     # the "handle-owned" partial Q_gain_hat
+
+    def gainPartial(self, f, stream=0):
+        import torch
+        d, keep = make_desc(self.nv, self.gl, self.sph, *self.args, 64, self.dir_range, self.max_chunk)
+        fh = np.ascontiguousarray(f.numpy(), dtype=np.float64)
+        qh = np.empty(2 * self.nv ** 3)
+        dp = ctypes.POINTER(ctypes.c_double)
+        rc = lib().bfsm_emu_collide(ctypes.byref(d), fh.ctypes.data_as(dp), None, qh.ctypes.data_as(dp))
+        if rc:
+            raise RuntimeError(f"bfsm_emu_collide rc={rc}")
+        self.qhat.copy_(torch.from_numpy(qh))
+
+    def finish(self, Q, f, stream=0):
+        import torch
+        L = lib()
+        dp = ctypes.POINTER(ctypes.c_double)
+        if not hasattr(L.bfsm_emu_finish, "_typed"):
+            from bfsm import capi
+            L.bfsm_emu_finish.argtypes = [ctypes.POINTER(capi.Desc), dp, dp, dp]
+            L.bfsm_emu_finish.restype = ctypes.c_int
+            L.bfsm_emu_finish._typed = True
+        d, keep = make_desc(self.nv, self.gl, self.sph, *self.args, 64, self.dir_range, self.max_chunk)
+        fh = np.ascontiguousarray(f.numpy(), dtype=np.float64)
+        qh = np.ascontiguousarray(self.qhat.numpy())
+        out = np.empty(self.nv ** 3)
+        rc = L.bfsm_emu_finish(ctypes.byref(d), fh.ctypes.data_as(dp), qh.ctypes.data_as(dp), out.ctypes.data_as(dp))
+        if rc:
+            raise RuntimeError(f"bfsm_emu_finish rc={rc}")
+        Q.copy_(torch.from_numpy(out))
