@@ -6,7 +6,7 @@ points from Python, with torch used only for device memory, streams and torch.di
 
 There is deliberately no CPU fallback: if libbfsm_hip.so is missing or no GPU is visible, construction fails.
 """
-from .capi import (BFSM_F32, BFSM_F64, BFSM_FLAG_PROFILE, KERNEL_NAMES, BfsmError, Counters, Desc, lib_path,
+from .capi import (BFSM_F32, BFSM_F64, BFSM_FLAG_EXACT_REDUCTIONS, BFSM_FLAG_PROFILE, KERNEL_NAMES, BfsmError, Counters, Desc, lib_path,
                    load_library)
 from .operator import HIPBoltzmannOperator, shard_range
 from .sharded import device_view, sharded_step
@@ -14,7 +14,7 @@ from .quadrature import GaussLegendreQuadrature, SphericalDesign
 from .bkw import bkw_solution, error_norms, reference_constants, perturbed_input
 
 __all__ = [
-    "BFSM_F32", "BFSM_F64", "BFSM_FLAG_PROFILE", "KERNEL_NAMES", "BfsmError", "Counters", "Desc", "lib_path",
+    "BFSM_F32", "BFSM_F64", "BFSM_FLAG_PROFILE", "BFSM_FLAG_EXACT_REDUCTIONS", "KERNEL_NAMES", "BfsmError", "Counters", "Desc", "lib_path",
     "load_library", "HIPBoltzmannOperator", "shard_range", "sharded_step", "device_view", "GaussLegendreQuadrature", "SphericalDesign",
     "bkw_solution", "error_norms", "reference_constants", "perturbed_input",
 ]

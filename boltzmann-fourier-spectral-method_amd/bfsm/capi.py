@@ -6,6 +6,7 @@ BFSM_OK = 0
 BFSM_F64 = 64
 BFSM_F32 = 32
 BFSM_FLAG_PROFILE = 1
+BFSM_FLAG_EXACT_REDUCTIONS = 2
 KERNEL_NAMES = ("fft_f", "gain_inv", "gain_line", "gain_fwd", "reduce", "tail")
 K_COUNT = len(KERNEL_NAMES)
 
@@ -40,6 +41,7 @@ class Counters(ctypes.Structure):
         ("kernel_alg_bytes", ctypes.c_double * K_COUNT),
         ("kernel_launches", ctypes.c_int * K_COUNT),
         ("n_chunks", ctypes.c_int), ("chunk_dirs", ctypes.c_int), ("n_dirs", ctypes.c_longlong),
+        ("moved_bytes_per_eval", ctypes.c_double), ("exact_reductions", ctypes.c_int), ("antipodal_merged", ctypes.c_int),
     ]
 
 

@@ -47,7 +47,12 @@ class HIPBoltzmannOperator:
         self._max_chunk = int(n)
 
     def setProfiling(self, on=True):
-        self._flags = capi.BFSM_FLAG_PROFILE if on else 0
+        self._flags = (self._flags | capi.BFSM_FLAG_PROFILE) if on else (self._flags & ~capi.BFSM_FLAG_PROFILE)
+
+    def setExactReductions(self, on=True):
+        """Opt-in SURVEY 8(f1) reductions (antipodal pairs + one forward FFT per radial node); default off."""
+        f = capi.BFSM_FLAG_EXACT_REDUCTIONS
+        self._flags = (self._flags | f) if on else (self._flags & ~f)
 
     def getBackendName(self):
         return (self._lib or capi.load_library()).bfsm_backend_name().decode()

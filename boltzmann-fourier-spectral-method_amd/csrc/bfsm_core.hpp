@@ -250,6 +250,18 @@ struct ReduceParams {        // Q_hat[l] = sum_segments beta1[r(seg)][|l|^2] * s
 };
 
 template <typename T>
+struct GainLineAccParams {   // KB', exact-reduction mode: sum over the directions of a segment BEFORE the forward FFT
+    const cx<T>* a1;         // [slot][lx][y][z]
+    const cx<T>* a2;
+    cx<T>* pseg;             // [segment][x][y][z]: x-forward transform of sum_d dirw[d] * A1_d * A2_d
+    const T* dirw;           // [n_dirs]
+    const Segment* segs;
+    const cx<T>* tw;
+    long long dir0;          // shard-local index of the chunk's first direction
+    int seg0;                // first segment of this chunk
+};
+
+template <typename T>
 struct TailInvParams {       // tail step 1: plane inverse transforms of Q_hat and beta2 * f_hat
     const cx<T>* qhat;
     const cx<T>* fhat;
@@ -396,6 +408,45 @@ BFSM_HD void body_gain_line(const GainLineParams<T>& prm, Ctx& ctx) {
     fft_line<N, -1, T>(a, lds, p, u, twr, ctx);
 #pragma unroll
     for (int m = 0; m < E; ++m) prm.a1[base + (size_t)(u + TT * m) * N * N] = a[m];
+}
+
+// KB' (exact-reduction mode).  grid = (N rows y, segments).  FFT linearity: beta1 depends on r only and the forward
+// transform is linear, so sum_s w_s FFT(A1_s * A2_s) = FFT(sum_s w_s A1_s * A2_s): the products of all directions of
+// a segment (same radial node) are summed in registers in PHYSICAL space and transformed forward once
+// (exact up to rounding order).
+template <int N, typename T, class Ctx>
+BFSM_HD void body_gain_line_acc(const GainLineAccParams<T>& prm, Ctx& ctx) {
+    constexpr int E = Wg<N>::E, TT = Wg<N>::T;
+    const int tid = ctx.tid(), p = tid % N, u = ctx.uniform(tid / N, N);
+    cx<T>* lds = ctx.template lds<cx<T>>();
+    cx<T> twr[E - 1];
+    load_twiddles<N, T>(twr, prm.tw, u, ctx);
+    const Segment seg = prm.segs[prm.seg0 + ctx.by()];
+    const size_t row = (size_t)ctx.bx() * N + p;
+    cx<T> acc[E];
+#pragma unroll
+    for (int m = 0; m < E; ++m) acc[m] = {(T)0, (T)0};
+    for (int d = seg.d0; d < seg.d0 + seg.n; ++d) {
+        const size_t base = (size_t)d * N * N * N + row;
+        cx<T> a[E], b[E];
+#pragma unroll
+        for (int m = 0; m < E; ++m) a[m] = prm.a1[base + (size_t)(u + TT * m) * N * N];
+#pragma unroll
+        for (int m = 0; m < E; ++m) b[m] = prm.a2[base + (size_t)(u + TT * m) * N * N];
+        fft_line<N, +1, T>(a, lds, p, u, twr, ctx);
+        fft_line<N, +1, T>(b, lds, p, u, twr, ctx);
+        const T w = prm.dirw[prm.dir0 + d];
+#pragma unroll
+        for (int m = 0; m < E; ++m) {
+            const cx<T> pr = cmul(a[m], b[m]);
+            acc[m].x += w * pr.x;
+            acc[m].y += w * pr.y;
+        }
+    }
+    fft_line<N, -1, T>(acc, lds, p, u, twr, ctx);
+    const size_t obase = (size_t)(prm.seg0 + ctx.by()) * N * N * N + row;
+#pragma unroll
+    for (int m = 0; m < E; ++m) prm.pseg[obase + (size_t)(u + TT * m) * N * N] = acc[m];
 }
 
 // KC.  grid = (N planes x, segments of the chunk).  (y,z) part of the forward transform + the direction sum of

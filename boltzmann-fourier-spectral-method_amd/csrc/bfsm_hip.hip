@@ -62,6 +62,7 @@ __global__ void __launch_bounds__((kernel_threads<kind, N>()), (kernel_min_waves
     else if constexpr (kind == K::Reduce) body_reduce<N, T>(prm, ctx);
     else if constexpr (kind == K::TailInv) body_tail_inv<N, T>(prm, ctx);
     else if constexpr (kind == K::TailLine) body_tail_line<N, T>(prm, ctx);
+    else if constexpr (kind == K::GainLineAcc) body_gain_line_acc<N, T>(prm, ctx);
 }
 
 // ---- HIP backend -----------------------------------------------------------------------------------------------
@@ -207,7 +208,7 @@ int bfsm_create(const bfsm_desc* desc, bfsm_handle* out) {
     }
     // the descriptor's host arrays are not referenced after create
     h->desc.gl_nodes = h->desc.gl_wts = h->desc.sph_wts = h->desc.sx = h->desc.sy = h->desc.sz = nullptr;
-    h->full_shard = h->info.dir_begin == 0 && h->info.dir_end == (long long)desc->n_gl * desc->n_sph;
+    h->full_shard = h->info.full_begin == 0 && h->info.full_end == (long long)desc->n_gl * desc->n_sph;
     if (rc == BFSM_OK) rc = check_hip(h, "bfsm_create");
     else if (h->be.first_error != hipSuccess) { (void)check_hip(h, "bfsm_create"); err = h->err; }
     if (rc != BFSM_OK) {
@@ -292,6 +293,9 @@ int bfsm_get_counters(bfsm_handle h, bfsm_counters* out) {
     c.n_chunks = (int)h->info.chunks.size();
     c.chunk_dirs = h->info.largest_chunk;
     c.n_dirs = h->info.n_dirs();
+    c.moved_bytes_per_eval = bfsm::moved_bytes_per_eval(h->info);
+    c.exact_reductions = h->info.exact_reductions ? 1 : 0;
+    c.antipodal_merged = h->info.antipodal ? 1 : 0;
     if (h->be.profile && !h->be.recs.empty()) {
         hipError_t e = hipStreamSynchronize(h->be.stream);
         if (e != hipSuccess) return fail(h, BFSM_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));

@@ -34,7 +34,15 @@ struct PlanInfo {
     int N = 0;
     int precision = 64;
     int n_gl = 0, n_sph = 0;
-    long long dir_begin = 0, dir_end = 0;  // global direction range of the shard
+    // Work units are EFFECTIVE directions e = r*sph_eff + s.  Reference-faithful mode: sph_eff = n_sph, weight_mult = 1
+    // (one unit per quadrature direction).  Exact-reduction mode on an antipodal design: sph_eff = n_sph/2,
+    // weight_mult = 2 (direction s and its antipode s + n_sph/2 give the identical product A1*A2).
+    int sph_eff = 0;
+    int weight_mult = 1;
+    bool exact_reductions = false;         // BFSM_FLAG_EXACT_REDUCTIONS
+    bool antipodal = false;                // design satisfies sigma_{s+M/2} == -sigma_s and w equal, bit-exactly
+    long long full_begin = 0, full_end = 0;  // the shard as given, in full quadrature directions b = r*n_sph + s
+    long long dir_begin = 0, dir_end = 0;  // the shard in effective directions
     int max_chunk = 1024;
     int groups = 8;                        // target workgroup columns per x-plane (>= 2 workgroups per CU)
     std::vector<Segment> segs;             // accumulation segments of all chunks, in slab order
@@ -75,8 +83,22 @@ inline PlanInfo make_plan(const bfsm_desc& d) {
     p.n_gl = d.n_gl;
     p.n_sph = d.n_sph;
     const long long B = (long long)d.n_gl * d.n_sph;
-    if (d.dir_begin == 0 && d.dir_end == 0) { p.dir_begin = 0; p.dir_end = B; }
-    else { p.dir_begin = d.dir_begin; p.dir_end = d.dir_end; }
+    if (d.dir_begin == 0 && d.dir_end == 0) { p.full_begin = 0; p.full_end = B; }
+    else { p.full_begin = d.dir_begin; p.full_end = d.dir_end; }
+    p.exact_reductions = (d.flags & BFSM_FLAG_EXACT_REDUCTIONS) != 0;
+    p.sph_eff = d.n_sph;
+    if (p.exact_reductions && d.n_sph % 2 == 0) {
+        const int h = d.n_sph / 2;
+        bool anti = true;
+        for (int s = 0; s < h && anti; ++s)
+            anti = d.sx[s + h] == -d.sx[s] && d.sy[s + h] == -d.sy[s] && d.sz[s + h] == -d.sz[s] &&
+                   d.sph_wts[s + h] == d.sph_wts[s];
+        if (anti) { p.antipodal = true; p.sph_eff = h; p.weight_mult = 2; }
+    }
+    // a shard of full directions maps to the proportional range of effective directions (monotone, so the ranks'
+    // ranges still tile the whole set exactly once)
+    p.dir_begin = p.full_begin * p.sph_eff / d.n_sph;
+    p.dir_end = p.full_end * p.sph_eff / d.n_sph;
     // Directions resident at once.  Sized for 288 GB of HBM: by default the whole shard (up to 1024 directions,
     // i.e. 8 GiB of A1'/A2' scratch at N=64 fp64) is one chunk, so an evaluation is ~8 launches.
     p.max_chunk = d.max_chunk > 0 ? d.max_chunk : 1024;
@@ -96,11 +118,11 @@ inline PlanInfo make_plan(const bfsm_desc& d) {
             // radial runs inside the chunk; every run is cut into `cuts` near-equal segments so that the chunk
             // offers at least `groups` accumulating workgroups per x-plane
             const long long g0 = p.dir_begin + o, g1 = g0 + c.n;
-            const int r_first = (int)(g0 / d.n_sph), r_last = (int)((g1 - 1) / d.n_sph);
+            const int r_first = (int)(g0 / p.sph_eff), r_last = (int)((g1 - 1) / p.sph_eff);
             const int runs = r_last - r_first + 1;
             const int cuts = (p.groups + runs - 1) / runs;
             for (int r = r_first; r <= r_last; ++r) {
-                long long a0 = (long long)r * d.n_sph, a1 = a0 + d.n_sph;
+                long long a0 = (long long)r * p.sph_eff, a1 = a0 + p.sph_eff;
                 if (a0 < g0) a0 = g0;
                 if (a1 > g1) a1 = g1;
                 const long long rl = a1 - a0;
@@ -153,7 +175,7 @@ HostTables<T> build_tables(const bfsm_desc& d, const PlanInfo& p) {
     t.dirw.resize((size_t)nd);
     for (long long i = 0; i < nd; ++i) {
         const long long b = p.dir_begin + i;
-        const int r = (int)(b / d.n_sph), s = (int)(b % d.n_sph);
+        const int r = (int)(b / p.sph_eff), s = (int)(b % p.sph_eff);   // s < n_sph/2 when antipodal pairs are merged
         // theta(l) = -(pi/(2L)) rho_r (l . sigma_s)   (FFTWBoltzmannOperator.cpp:205-209), separable in lx, ly, lz
         const long double k = -((long double)pi / (2.0L * (long double)d.L)) * (long double)d.gl_nodes[r];
         for (int n = 0; n < N; ++n) {
@@ -166,7 +188,7 @@ HostTables<T> build_tables(const bfsm_desc& d, const PlanInfo& p) {
             t.phz[(size_t)i * N + n] = {(T)cosl(az), (T)sinl(az)};
         }
         // weight = fft_scale * gl_wts[r] * spherical_wts[s] * pow(gl_nodes[r], gamma + 2)   (cpp:252)
-        t.dirw[(size_t)i] = (T)(fft_scale * d.gl_wts[r] * d.sph_wts[s] * std::pow(d.gl_nodes[r], d.gamma + 2));
+        t.dirw[(size_t)i] = (T)(p.weight_mult * (fft_scale * d.gl_wts[r] * d.sph_wts[s] * std::pow(d.gl_nodes[r], d.gamma + 2)));
     }
     t.beta1.resize((size_t)d.n_gl * p.n2stride);
     t.beta2.assign((size_t)p.n2stride, (T)0);
@@ -186,7 +208,7 @@ HostTables<T> build_tables(const bfsm_desc& d, const PlanInfo& p) {
 }
 
 // Kernel identifiers the backend dispatches on.
-enum class K { TileFwdReal, LineFwd, LineInv, TileFwd, TileInv, GainInv, GainLine, GainFwd, Reduce, TailInv, TailLine };
+enum class K { TileFwdReal, LineFwd, LineInv, TileFwd, TileInv, GainInv, GainLine, GainFwd, Reduce, TailInv, TailLine, GainLineAcc };
 
 // Device-resident state of one handle.  `Backend` supplies:
 //   void* alloc(size_t), void release(void*), void upload(void* dst, const void* src, size_t), void zero(void*, size_t)
@@ -212,6 +234,10 @@ struct Pipeline {
     T* beta1 = nullptr;
     T* beta2 = nullptr;
     Segment* segs = nullptr;
+    // exact-reduction mode only
+    cx<T>* pseg = nullptr;        // [segment][x][y][z]
+    Segment* segs_unit = nullptr; // one single-slot segment per pseg entry, same r
+    T* ones = nullptr;
     size_t slab_count = 0;
 
     template <typename U>
@@ -240,17 +266,25 @@ struct Pipeline {
         ok = ok && (slab = (cx<T>*)be->alloc((slab_count ? slab_count : 1) * G * sizeof(cx<T>)));
         ok = ok && dev_copy(tw, t.tw) && dev_copy(phx, t.phx) && dev_copy(phy, t.phy) && dev_copy(phz, t.phz);
         ok = ok && dev_copy(dirw, t.dirw) && dev_copy(beta1, t.beta1) && dev_copy(beta2, t.beta2) && dev_copy(segs, plan.segs);
+        if (ok && plan.exact_reductions) {
+            std::vector<Segment> unit(plan.segs.size());
+            for (size_t i = 0; i < unit.size(); ++i) unit[i] = Segment{(int)i, 1, plan.segs[i].r, 0};
+            std::vector<T> one(unit.size() ? unit.size() : 1, (T)1);
+            ok = ok && (pseg = (cx<T>*)be->alloc((slab_count ? slab_count : 1) * G * sizeof(cx<T>)));
+            ok = ok && dev_copy(segs_unit, unit) && dev_copy(ones, one);
+        }
         if (!ok) { err = "device allocation failed"; return BFSM_ERR_NOMEM; }
         return BFSM_OK;
     }
 
     void destroy() {
         if (!be) return;
-        void* ptrs[] = {fhat, tg, tl, qhat, a1, a2, slab, tw, phx, phy, phz, dirw, beta1, beta2, segs};
+        void* ptrs[] = {fhat, tg, tl, qhat, a1, a2, slab, tw, phx, phy, phz, dirw, beta1, beta2, segs, pseg, segs_unit, ones};
         for (void* p : ptrs) if (p) be->release(p);
         fhat = tg = tl = qhat = a1 = a2 = slab = tw = phx = phy = phz = nullptr;
         dirw = beta1 = beta2 = nullptr;
         segs = nullptr;
+        pseg = nullptr; segs_unit = nullptr; ones = nullptr;
     }
 
     double cbytes() const { return (double)sizeof(cx<T>); }
@@ -272,12 +306,23 @@ struct Pipeline {
             const int ga = (c.n + c.per_group - 1) / c.per_group;
             be->mark(BFSM_K_GAIN_INV, 2.0 * c.n * Gc);
             be->template launch<K::GainInv, T>(N, ga, ka, N);
-            GainLineParams<T> kb{a1, a2, tw};
-            be->mark(BFSM_K_GAIN_LINE, 3.0 * c.n * Gc);
-            be->template launch<K::GainLine, T>(N, c.n, kb, N);
-            GainFwdParams<T> kc{a1, slab, dirw, segs, tw, c.dir0, c.seg0};
-            be->mark(BFSM_K_GAIN_FWD, 1.0 * c.n * Gc);
-            be->template launch<K::GainFwd, T>(N, c.n_seg, kc, N);
+            if (!plan.exact_reductions) {
+                GainLineParams<T> kb{a1, a2, tw};
+                be->mark(BFSM_K_GAIN_LINE, 3.0 * c.n * Gc);
+                be->template launch<K::GainLine, T>(N, c.n, kb, N);
+                GainFwdParams<T> kc{a1, slab, dirw, segs, tw, c.dir0, c.seg0};
+                be->mark(BFSM_K_GAIN_FWD, 1.0 * c.n * Gc);
+                be->template launch<K::GainFwd, T>(N, c.n_seg, kc, N);
+            } else {
+                GainLineAccParams<T> kb{a1, a2, pseg, dirw, segs, tw, c.dir0, c.seg0};
+                be->mark(BFSM_K_GAIN_LINE, (2.0 * c.n + c.n_seg) * Gc);
+                be->template launch<K::GainLineAcc, T>(N, c.n_seg, kb, N);
+            }
+        }
+        if (plan.exact_reductions && slab_count) {   // one forward tile pass per segment, all chunks at once
+            GainFwdParams<T> kc{pseg, slab, ones, segs_unit, tw, 0, 0};
+            be->mark(BFSM_K_GAIN_FWD, 1.0 * (double)slab_count * Gc);
+            be->template launch<K::GainFwd, T>(N, (int)slab_count, kc, N);
         }
         ReduceParams<T> kr{slab, qhat, beta1, segs, (int)slab_count, plan.n2stride};
         be->mark(BFSM_K_REDUCE, ((double)slab_count + 1.0) * Gc);
@@ -315,9 +360,19 @@ struct Pipeline {
     }
 };
 
+// SURVEY.md 8(d) model for this shard, always in FULL quadrature directions (3 FFTs per direction, read + write each)
 inline double alg_bytes_per_eval(const PlanInfo& p) {
     const double c = p.precision == BFSM_F64 ? 16.0 : 8.0;
-    return (6.0 * (double)p.n_dirs() + 9.0) * (double)p.G() * c;
+    return (6.0 * (double)(p.full_end - p.full_begin) + 9.0) * (double)p.G() * c;
+}
+
+// Bytes the launch sequence actually moves (model): equals the figure above in the faithful mode (+ slabs); in the
+// exact-reduction mode 4 array passes per effective direction + 2 per segment.
+inline double moved_bytes_per_eval(const PlanInfo& p) {
+    const double c = p.precision == BFSM_F64 ? 16.0 : 8.0;
+    const double G = (double)p.G(), n = (double)p.n_dirs(), sg = (double)p.segs.size();
+    if (!p.exact_reductions) return (6.0 * n + 2.0 * sg + 9.0) * G * c;
+    return (4.0 * n + 4.0 * sg + 9.0) * G * c;
 }
 
 }  // namespace bfsm

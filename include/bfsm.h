@@ -41,7 +41,15 @@ enum {
 
 enum {
     BFSM_FLAG_NONE = 0,
-    BFSM_FLAG_PROFILE = 1 /* record HIP events around every kernel launch (bfsm_get_counters) */
+    BFSM_FLAG_PROFILE = 1, /* record HIP events around every kernel launch (bfsm_get_counters) */
+    /* Opt-in exact work reductions; results equal the faithful path up to rounding order (~1e-16):
+     *  (i)  antipodal pairs: if the spherical rule satisfies sigma_{s+M/2} == -sigma_s with equal weights (all shipped
+     *       symmetric designs do, bit-exactly), direction s+M/2 gives the same product A1*A2 as s, so only M/2
+     *       directions per radial node are evaluated, with doubled weight; otherwise this part is skipped;
+     *  (ii) FFT linearity: the products of all directions of a radial node are summed in physical space and
+     *       forward-transformed once, instead of one forward FFT per direction.
+     * The default (flag clear) evaluates every direction with its own three FFTs, like the reference. */
+    BFSM_FLAG_EXACT_REDUCTIONS = 2
 };
 
 typedef struct bfsm_plan* bfsm_handle;
@@ -85,7 +93,11 @@ typedef struct bfsm_counters {
     int kernel_launches[BFSM_K_COUNT];
     int n_chunks;
     int chunk_dirs;                       /* directions in the largest chunk                               */
-    long long n_dirs;                     /* directions of this shard                                      */
+    long long n_dirs;                     /* work units of this shard (directions; antipodal pairs if merged) */
+    double moved_bytes_per_eval;          /* bytes the launch sequence moves (model); == alg bytes + slabs unless
+                                             BFSM_FLAG_EXACT_REDUCTIONS is set                                */
+    int exact_reductions;                 /* 1 if the flag is active                                          */
+    int antipodal_merged;                 /* 1 if antipodal pairs were merged                                 */
 } bfsm_counters;
 
 /* == BoltzmannOperator<CUDA_Backend>::initialize() (CUDABoltzmannOperator.cu:28-115): allocates all device

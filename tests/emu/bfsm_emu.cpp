@@ -103,6 +103,7 @@ struct EmuBackend {
         else if constexpr (kind == K::Reduce) body_reduce<N, T>(prm, ctx);
         else if constexpr (kind == K::TailInv) body_tail_inv<N, T>(prm, ctx);
         else if constexpr (kind == K::TailLine) body_tail_line<N, T>(prm, ctx);
+        else if constexpr (kind == K::GainLineAcc) body_gain_line_acc<N, T>(prm, ctx);
     }
 
     template <bfsm::K kind, int N, typename T, class P>

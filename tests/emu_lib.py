@@ -27,19 +27,19 @@ def lib():
     return _LIB
 
 
-def make_desc(nv, gl, sph, gamma, b_gamma, L, precision=64, dir_range=(0, 0), max_chunk=0):
+def make_desc(nv, gl, sph, gamma, b_gamma, L, precision=64, dir_range=(0, 0), max_chunk=0, flags=0):
     """gl = (nodes, weights), sph = (x, y, z, w).  Returns (Desc, keepalive)."""
     from bfsm import capi
     dp = ctypes.POINTER(ctypes.c_double)
     keep = [np.ascontiguousarray(a, dtype=np.float64) for a in (gl[0], gl[1], sph[3], sph[0], sph[1], sph[2])]
     d = capi.Desc(nv, nv, nv, len(keep[0]), len(keep[2]), *[a.ctypes.data_as(dp) for a in keep],
-                  gamma, b_gamma, L, precision, 0, dir_range[0], dir_range[1], max_chunk, 0)
+                  gamma, b_gamma, L, precision, 0, dir_range[0], dir_range[1], max_chunk, flags)
     return d, keep
 
 
-def collide(f, gl, sph, gamma, b_gamma, L, precision=64, dir_range=(0, 0), max_chunk=0, want_Q=True):
+def collide(f, gl, sph, gamma, b_gamma, L, precision=64, dir_range=(0, 0), max_chunk=0, want_Q=True, flags=0):
     nv = f.shape[0]
-    d, keep = make_desc(nv, gl, sph, gamma, b_gamma, L, precision, dir_range, max_chunk)
+    d, keep = make_desc(nv, gl, sph, gamma, b_gamma, L, precision, dir_range, max_chunk, flags)
     f = np.ascontiguousarray(f, dtype=np.float64)
     Q = np.empty_like(f)
     qh = np.empty(f.shape + (2,))
@@ -68,11 +68,12 @@ def fft3d(a, sign, precision=64):
     return buf
 
 
-def plan(nv, n_gl, n_sph, precision=64, dir_range=(0, 0), max_chunk=0):
+def plan(nv, n_gl, n_sph, precision=64, dir_range=(0, 0), max_chunk=0, flags=0, sph=None):
     """Returns (chunks, segments): chunk rows (n_seg, dir0, n, per_group, seg0), segment rows (chunk, d0, n, r)."""
     gl = (np.ones(n_gl), np.ones(n_gl))
-    sph = (np.ones(n_sph), np.zeros(n_sph), np.zeros(n_sph), np.ones(n_sph))
-    d, keep = make_desc(nv, gl, sph, 0.0, 1.0, 1.0, precision, dir_range, max_chunk)
+    if sph is None:
+        sph = (np.ones(n_sph), np.zeros(n_sph), np.zeros(n_sph), np.ones(n_sph))
+    d, keep = make_desc(nv, gl, sph, 0.0, 1.0, 1.0, precision, dir_range, max_chunk, flags)
     crow = (ctypes.c_int * (5 * 4096))()
     srow = (ctypes.c_int * (5 * 65536))()
     nseg = ctypes.c_int()

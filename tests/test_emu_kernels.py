@@ -113,3 +113,50 @@ def test_plan_rejects_unsupported():
         E.plan(128, 2, 6, 64)            # N=128 needs fp32
     with pytest.raises(ValueError):
         E.plan(16, 2, 6, 64, (5, 40))    # shard beyond n_gl*n_sph
+
+
+EXACT = 2   # BFSM_FLAG_EXACT_REDUCTIONS
+
+
+@pytest.mark.parametrize("nv,n_gl,n_sph,max_chunk", [(16, 3, 12, 0), (16, 3, 12, 5), (32, 2, 6, 0)])
+def test_exact_reductions_match_oracle(oracle, nv, n_gl, n_sph, max_chunk):
+    """antipodal pairs merged + one forward FFT per radial-node segment == all directions, to rounding."""
+    f, _, L, _ = oracle.bkw(nv)
+    f = oracle.perturbed_input(f)
+    gl = oracle.gauss_legendre(n_gl, 0.0, R)
+    sph = oracle.spherical_design(n_sph)
+    Qo, qo = oracle.collide(f, gl, sph, GAMMA, B_GAMMA, L, return_qhat=True)
+    Q, qhat = E.collide(f, gl, sph, GAMMA, B_GAMMA, L, 64, max_chunk=max_chunk, flags=EXACT)
+    assert np.abs(qhat - qo).max() <= 1e-12 * np.abs(qo).max()
+    assert np.abs(Q - Qo).max() <= 1e-12 * np.abs(Qo).max()
+    chunks, segs = E.plan(nv, n_gl, n_sph, 64, (0, 0), max_chunk, flags=EXACT, sph=sph)
+    assert sum(c[2] for c in chunks) == n_gl * n_sph // 2          # half the directions are evaluated
+
+
+def test_exact_reductions_without_antipodal_structure(oracle):
+    """A rule that is not antipodal (pairs broken by a permutation, unequal weights) only gets the linearity part."""
+    f, _, L, _ = oracle.bkw(16)
+    f = oracle.perturbed_input(f)
+    gl = oracle.gauss_legendre(2, 0.0, R)
+    x, y, z, w = oracle.spherical_design(12)
+    perm = np.array([0, 7, 2, 3, 4, 5, 6, 1, 8, 9, 10, 11])
+    sph = (x[perm].copy(), y[perm].copy(), z[perm].copy(), w * np.linspace(0.9, 1.1, 12))
+    Qo, qo = oracle.collide(f, gl, sph, GAMMA, B_GAMMA, L, return_qhat=True)
+    Q, qhat = E.collide(f, gl, sph, GAMMA, B_GAMMA, L, 64, flags=EXACT)
+    assert np.abs(qhat - qo).max() <= 1e-12 * np.abs(qo).max()
+    assert np.abs(Q - Qo).max() <= 1e-12 * np.abs(Qo).max()
+    chunks, _ = E.plan(16, 2, 12, 64, flags=EXACT, sph=sph)
+    assert sum(c[2] for c in chunks) == 24                         # nothing merged
+
+
+def test_exact_reductions_sharded(oracle):
+    f, _, L, _ = oracle.bkw(16)
+    f = oracle.perturbed_input(f)
+    gl = oracle.gauss_legendre(3, 0.0, R)
+    sph = oracle.spherical_design(12)
+    _, whole = oracle.collide(f, gl, sph, GAMMA, B_GAMMA, L, return_qhat=True)
+    parts = 0
+    for rng_ in ((0, 7), (7, 20), (20, 36)):      # full-direction shards map to proportional effective ranges
+        _, qh = E.collide(f, gl, sph, GAMMA, B_GAMMA, L, 64, dir_range=rng_, want_Q=False, flags=EXACT)
+        parts = parts + qh
+    assert np.abs(parts - whole).max() <= 1e-12 * np.abs(whole).max()

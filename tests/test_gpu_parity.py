@@ -23,7 +23,7 @@ def torch_cuda():
     return torch
 
 
-def _make(bfsm, nv, n_gl, n_sph, precision=64, shard=None, max_chunk=0, profile=False):
+def _make(bfsm, nv, n_gl, n_sph, precision=64, shard=None, max_chunk=0, profile=False, exact=False):
     c = bfsm.reference_constants()
     L = c["L"]
     op = bfsm.HIPBoltzmannOperator(bfsm.GaussLegendreQuadrature(n_gl, 0.0, c["R"]), bfsm.SphericalDesign(n_sph),
@@ -34,6 +34,7 @@ def _make(bfsm, nv, n_gl, n_sph, precision=64, shard=None, max_chunk=0, profile=
     if max_chunk:
         op.setMaxChunk(max_chunk)
     op.setProfiling(profile)
+    op.setExactReductions(exact)
     op.initialize()
     return op
 
@@ -134,11 +135,11 @@ class _DevView:
         return torch.as_tensor(self, device="cuda")
 
 
-def _sharded_collide(torch, bfsm, nv, n_gl, n_sph, f, P, precision=64, max_chunk=0):
+def _sharded_collide(torch, bfsm, nv, n_gl, n_sph, f, P, precision=64, max_chunk=0, exact=False):
     """P handles with disjoint direction shards on ONE device; the sum of their partial Q_gain_hat buffers is what
     the RCCL all-reduce produces on a multi-GPU node; finish() on shard 0 completes the evaluation."""
-    ops = [_make(bfsm, nv, n_gl, n_sph, precision, shard=bfsm.shard_range(n_gl * n_sph, r, P), max_chunk=max_chunk)
-           for r in range(P)]
+    ops = [_make(bfsm, nv, n_gl, n_sph, precision, shard=bfsm.shard_range(n_gl * n_sph, r, P), max_chunk=max_chunk,
+                 exact=exact) for r in range(P)]
     views = []
     for op in ops:
         op.gainPartial(f)
@@ -242,3 +243,38 @@ def test_cpp_driver_reproduces_published_norms(torch_cuda):
     row = GOLD["published"][0]
     for k in ("L1", "L2", "Linf"):
         assert got[k] == pytest.approx(row[k], rel=2e-5), (k, got, text)     # std::cout prints 6 significant digits
+
+
+@pytest.mark.parametrize("nv,n_gl,n_sph", [(16, 8, 32), (32, 8, 48), (64, 2, 12)])
+def test_exact_reductions_match_oracle(torch_cuda, oracle, nv, n_gl, n_sph):
+    """Opt-in SURVEY 8(f1) mode (antipodal pairs merged, one forward FFT per radial-node segment) vs the oracle."""
+    import bfsm
+    f_h = bfsm.perturbed_input(bfsm.bkw_solution(nv)[0])
+    op = _make(bfsm, nv, n_gl, n_sph, exact=True)
+    assert op.counters().antipodal_merged == 1 and op.counters().n_dirs == n_gl * n_sph // 2
+    got = _collide(torch_cuda, op, f_h)
+    ref = _oracle(oracle, f_h, n_gl, n_sph)
+    assert np.abs(got - ref).max() <= TOL64 * np.abs(ref).max()
+    op.destroy()
+
+
+def test_exact_reductions_full_size_and_shards(torch_cuda):
+    """cfg3 / cfg4 sizes: exact-reduction result == faithful result to rounding, also through 8 direction shards;
+    and the published N=64, M_gl=64 BKW norms are reproduced in this mode too."""
+    import bfsm
+    torch = torch_cuda
+    nv, n_gl = 64, 16
+    f_h = bfsm.perturbed_input(bfsm.bkw_solution(nv)[0])
+    f = torch.from_numpy(f_h).cuda()
+    for n_sph in (48, 156):
+        a = _collide(torch, _make(bfsm, nv, n_gl, n_sph), f_h)
+        b = _collide(torch, _make(bfsm, nv, n_gl, n_sph, exact=True), f_h)
+        assert np.abs(a - b).max() <= 1e-13 * np.abs(a).max()
+        c = _sharded_collide(torch, bfsm, nv, n_gl, n_sph, f, 8, exact=True)
+        assert np.abs(a - c).max() <= 1e-13 * np.abs(a).max()
+    row = [r for r in GOLD["published"] if r["nv"] == 64 and r["n_sph"] == 12][0]
+    fb, q_exact, _, dv = bfsm.bkw_solution(64)
+    got = _collide(torch, _make(bfsm, 64, 64, 12, exact=True), fb)
+    l1, l2, linf = bfsm.error_norms(got, q_exact, dv)
+    assert abs(l2 - row["L2"]) <= 1e-10 and l2 == pytest.approx(row["L2"], rel=6e-9)
+    assert linf == pytest.approx(row["Linf"], rel=6e-9)
