@@ -382,7 +382,7 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
         fft_tile<N, +1, T>(v, lds, p, u, twr, ctx);
         cx<T>* dst = (conj ? prm.a2 : prm.a1) + ((size_t)d * N + lxi) * N * N;
 #pragma unroll
-        for (int m = 0; m < E; ++m) dst[(size_t)(u + TT * m) * N + p] = v[m];  // [y = u + T m][z = p]
+        for (int m = 0; m < E; ++m) ctx.st_stream(dst + (size_t)(u + TT * m) * N + p, v[m]);  // [y = u + T m][z = p]
     }
 }
 
@@ -398,16 +398,16 @@ BFSM_HD void body_gain_line(const GainLineParams<T>& prm, Ctx& ctx) {
     load_twiddles<N, T>(twr, prm.tw, u, ctx);
     cx<T> a[E], b[E];
 #pragma unroll
-    for (int m = 0; m < E; ++m) a[m] = prm.a1[base + (size_t)(u + TT * m) * N * N];
+    for (int m = 0; m < E; ++m) a[m] = ctx.ld_stream(prm.a1 + base + (size_t)(u + TT * m) * N * N);
 #pragma unroll
-    for (int m = 0; m < E; ++m) b[m] = prm.a2[base + (size_t)(u + TT * m) * N * N];
+    for (int m = 0; m < E; ++m) b[m] = ctx.ld_stream(prm.a2 + base + (size_t)(u + TT * m) * N * N);
     fft_line<N, +1, T>(a, lds, p, u, twr, ctx);
     fft_line<N, +1, T>(b, lds, p, u, twr, ctx);
 #pragma unroll
     for (int m = 0; m < E; ++m) a[m] = cmul(a[m], b[m]);
     fft_line<N, -1, T>(a, lds, p, u, twr, ctx);
 #pragma unroll
-    for (int m = 0; m < E; ++m) prm.a1[base + (size_t)(u + TT * m) * N * N] = a[m];
+    for (int m = 0; m < E; ++m) ctx.st_stream(prm.a1 + base + (size_t)(u + TT * m) * N * N, a[m]);
 }
 
 // KB' (exact-reduction mode).  grid = (N rows y, segments).  FFT linearity: beta1 depends on r only and the forward
@@ -430,9 +430,9 @@ BFSM_HD void body_gain_line_acc(const GainLineAccParams<T>& prm, Ctx& ctx) {
         const size_t base = (size_t)d * N * N * N + row;
         cx<T> a[E], b[E];
 #pragma unroll
-        for (int m = 0; m < E; ++m) a[m] = prm.a1[base + (size_t)(u + TT * m) * N * N];
+        for (int m = 0; m < E; ++m) a[m] = ctx.ld_stream(prm.a1 + base + (size_t)(u + TT * m) * N * N);
 #pragma unroll
-        for (int m = 0; m < E; ++m) b[m] = prm.a2[base + (size_t)(u + TT * m) * N * N];
+        for (int m = 0; m < E; ++m) b[m] = ctx.ld_stream(prm.a2 + base + (size_t)(u + TT * m) * N * N);
         fft_line<N, +1, T>(a, lds, p, u, twr, ctx);
         fft_line<N, +1, T>(b, lds, p, u, twr, ctx);
         const T w = prm.dirw[prm.dir0 + d];
@@ -468,7 +468,7 @@ BFSM_HD void body_gain_fwd(const GainFwdParams<T>& prm, Ctx& ctx) {
         const cx<T>* src = prm.p + ((size_t)d * N + x) * N * N;
         cx<T> v[E];
 #pragma unroll
-        for (int m = 0; m < E; ++m) v[m] = src[(u + TT * m) * N + p];  // [y = u + T m][z = p]
+        for (int m = 0; m < E; ++m) v[m] = ctx.ld_stream(src + (u + TT * m) * N + p);  // [y = u + T m][z = p]
         fft_tile<N, -1, T>(v, lds, p, u, twr, ctx);
         const T w = prm.dirw[prm.dir0 + d];
 #pragma unroll

@@ -26,6 +26,22 @@ struct DevCtx {
     }
     template <class U>
     __device__ __forceinline__ U* lds() const { return reinterpret_cast<U*>(smem); }
+    // Once-touched scratch (A1', A2', P'): nontemporal accesses keep the streams from evicting the small hot set
+    // (f_hat planes, tables) out of L2.
+    template <class T>
+    __device__ __forceinline__ cx<T> ld_stream(const cx<T>* p) const {
+        typedef T vec2 __attribute__((ext_vector_type(2)));
+        const vec2 r = __builtin_nontemporal_load(reinterpret_cast<const vec2*>(p));
+        return cx<T>{r.x, r.y};
+    }
+    template <class T>
+    __device__ __forceinline__ void st_stream(cx<T>* p, cx<T> v) const {
+        typedef T vec2 __attribute__((ext_vector_type(2)));
+        vec2 r;
+        r.x = v.x;
+        r.y = v.y;
+        __builtin_nontemporal_store(r, reinterpret_cast<vec2*>(p));
+    }
     // read-only table element through the constant address space: with a wave-uniform address the compiler
     // emits s_load (scalar data cache, SGPR result) even when the kernel also stores to global memory
     template <class T>

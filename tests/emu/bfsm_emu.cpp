@@ -8,6 +8,7 @@
 #define BFSM_HD inline __attribute__((always_inline))
 #include <ucontext.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -29,16 +30,25 @@ struct EmuCtx {
     int uniform(int v, int) const { return v; }
     template <class U> U* lds() const { return reinterpret_cast<U*>(smem); }
     template <class U> U ldc(const U* p) const { return *p; }
-    void sync();
+    template <class U> U ld_stream(const U* p) const { return *p; }
+    template <class U> void st_stream(U* p, U v) const { *p = v; }
+    void sync();       // workgroup barrier
+    void wave_sync();  // ordering point inside one wave of 64 threads
 };
 
+// Cooperative scheduler.  A thread runs until it reaches a barrier; a workgroup barrier releases when every live
+// thread of the block waits at one, a wave barrier when every live thread of that wave waits at one.  Waves are
+// advanced one after the other as far as they can go, so code that relies on another WAVE having executed something
+// without a workgroup barrier in between reads stale LDS here (the emulation is adversarial on purpose).
 struct Sched {
     static constexpr size_t STACK = 256 * 1024;
+    enum State : char { RUN = 0, AT_WAVE = 1, AT_BLOCK = 2, DONE = 3 };
     ucontext_t main_ctx;
     std::vector<ucontext_t> ctxs;
     std::vector<char> stacks;
-    std::vector<char> done;
+    std::vector<char> state;
     int current = -1;
+    bool deadlock = false;
     void (*entry)(void*, EmuCtx&) = nullptr;
     void* arg = nullptr;
     std::vector<EmuCtx> ectx;
@@ -48,15 +58,15 @@ struct Sched {
         Sched* s = active();
         const int me = s->current;
         s->entry(s->arg, s->ectx[me]);
-        s->done[me] = 1;
+        s->state[me] = DONE;
         swapcontext(&s->ctxs[me], &s->main_ctx);
     }
-    void yield() { const int me = current; swapcontext(&ctxs[me], &main_ctx); }
+    void yield(State st) { const int me = current; state[me] = st; swapcontext(&ctxs[me], &main_ctx); }
 
     void run_block(int nthreads, int bx, int by, unsigned char* smem, void (*fn)(void*, EmuCtx&), void* a) {
         entry = fn; arg = a;
         if ((int)ctxs.size() < nthreads) { ctxs.resize(nthreads); stacks.resize((size_t)nthreads * STACK); }
-        done.assign(nthreads, 0);
+        state.assign(nthreads, RUN);
         ectx.resize(nthreads);
         active() = this;
         for (int t = 0; t < nthreads; ++t) {
@@ -67,18 +77,48 @@ struct Sched {
             ctxs[t].uc_link = &main_ctx;
             makecontext(&ctxs[t], (void (*)())trampoline, 0);
         }
-        int remaining = nthreads;
-        while (remaining > 0) {   // one round = every live thread runs up to its next barrier (or to its end)
-            for (int t = 0; t < nthreads; ++t) {
-                if (done[t]) continue;
-                current = t;
-                swapcontext(&main_ctx, &ctxs[t]);
-                if (done[t]) --remaining;
+        const int nwaves = (nthreads + 63) / 64;
+        for (;;) {
+            bool progressed = false, all_done = true;
+            for (int w = 0; w < nwaves; ++w) {
+                const int t0 = w * 64, t1 = std::min(nthreads, t0 + 64);
+                bool again = true;
+                while (again) {          // advance this wave as far as it can go
+                    again = false;
+                    for (int t = t0; t < t1; ++t) {
+                        if (state[t] != RUN) continue;
+                        current = t;
+                        swapcontext(&main_ctx, &ctxs[t]);
+                        progressed = true;
+                    }
+                    bool at_wave = false, others = false;
+                    for (int t = t0; t < t1; ++t) {
+                        if (state[t] == AT_WAVE) at_wave = true;
+                        else if (state[t] != DONE) others = true;
+                    }
+                    if (at_wave && !others) {   // whole wave (minus finished lanes) at the wave barrier: release
+                        for (int t = t0; t < t1; ++t) if (state[t] == AT_WAVE) state[t] = RUN;
+                        again = true;
+                    }
+                }
             }
+            bool at_block = false, others = false;
+            for (int t = 0; t < nthreads; ++t) {
+                if (state[t] == AT_BLOCK) at_block = true;
+                else if (state[t] != DONE) others = true;
+                if (state[t] != DONE) all_done = false;
+            }
+            if (all_done) break;
+            if (at_block && !others) {
+                for (int t = 0; t < nthreads; ++t) if (state[t] == AT_BLOCK) state[t] = RUN;
+                continue;
+            }
+            if (!progressed) { deadlock = true; break; }   // mismatched barriers
         }
     }
 };
-inline void EmuCtx::sync() { sched->yield(); }
+inline void EmuCtx::sync() { sched->yield(Sched::AT_BLOCK); }
+inline void EmuCtx::wave_sync() { sched->yield(Sched::AT_WAVE); }
 
 struct EmuBackend {
     Sched sched;
@@ -87,6 +127,7 @@ struct EmuBackend {
     void release(void* p) { std::free(p); }
     void upload(void* dst, const void* src, size_t bytes) { std::memcpy(dst, src, bytes); }
     void mark(int, double) {}
+    bool failed = false;   // a block ended with threads stuck at mismatched barriers
 
     template <bfsm::K kind, int N, typename T, class P>
     static void body(void* a, EmuCtx& ctx) {
@@ -113,7 +154,10 @@ struct EmuBackend {
         P copy = prm;
         for (int by = 0; by < gy; ++by)
             for (int bx = 0; bx < gx; ++bx)
+            {
                 sched.run_block(threads, bx, by, smem.data(), &body<kind, N, T, P>, &copy);
+                if (sched.deadlock) failed = true;
+            }
     }
 
     template <bfsm::K kind, typename T, class P>
@@ -144,7 +188,7 @@ int collide_t(const bfsm_desc* d, const double* f, double* Q, double* qhat_out) 
     }
     if (Q) p.finish(Q, f);
     p.destroy();
-    return 0;
+    return be.failed ? 99 : 0;
 }
 
 // Tail only: f_hat is recomputed (gain of an empty shard), qhat_in replaces the handle's buffer (what the all-reduce
@@ -163,7 +207,7 @@ int finish_t(const bfsm_desc* d, const double* f, const double* qhat_in, double*
     for (size_t i = 0; i < G; ++i) p.qhat[i] = {(T)qhat_in[2 * i], (T)qhat_in[2 * i + 1]};
     p.finish(Q, f);
     p.destroy();
-    return 0;
+    return be.failed ? 99 : 0;
 }
 
 template <typename T>
@@ -185,7 +229,7 @@ int fft3d_t(int N, double* data, int batch, int sign) {
     p.fft3d(buf.data(), batch, sign);
     for (size_t i = 0; i < total; ++i) { data[2 * i] = (double)buf[i].x; data[2 * i + 1] = (double)buf[i].y; }
     p.tw = nullptr;
-    return 0;
+    return be.failed ? 99 : 0;
 }
 
 }  // namespace emu
