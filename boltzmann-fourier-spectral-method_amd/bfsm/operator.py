@@ -107,6 +107,12 @@ class HIPBoltzmannOperator:
         self._require(f_in, Q)
         self._check(self._lib.bfsm_finish(self._h, _ptr(Q), _ptr(f_in), ctypes.c_void_p(stream)))
 
+    def finishPartial(self, Q, f_in, with_loss, stream=0):
+        """Q = Re IFFT(this shard's partial Q_gain_hat) [- loss term if with_loss]; the caller sums Q over ranks."""
+        self._require(f_in, Q)
+        self._check(self._lib.bfsm_finish_partial(self._h, _ptr(Q), _ptr(f_in), 1 if with_loss else 0,
+                                                  ctypes.c_void_p(stream)))
+
     def qhatBuffer(self):
         """(device pointer, n_elems, precision) of the partial Q_gain_hat owned by the handle."""
         n = ctypes.c_size_t()

@@ -6,12 +6,24 @@ host-emulated operator in the world-size-2 gloo tests.  `qhat` is a tensor view 
 """
 
 
-def sharded_step(op, qhat, Q, f, dist=None, stream=0):
-    """One collision evaluation on this rank's shard.  With dist=None it degenerates to the single-device path."""
+def sharded_step(op, qhat, Q, f, dist=None, stream=0, reduce_spectral=False):
+    """One collision evaluation on this rank's shard.  With dist=None it degenerates to the single-device path.
+
+    Default route (reduce_spectral=False): every rank inverse-transforms its own partial Q_gain_hat (the transform
+    is linear), rank 0 also subtracts the loss term, and the ONE collective sums the real Q (G doubles: half the
+    bytes of Q_hat, and nothing runs after the collective).  reduce_spectral=True is the textbook route: sum the
+    complex Q_gain_hat buffers (2G reals), then run the tail on every rank.
+    """
+    multi = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
     op.gainPartial(f, stream)
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(qhat)            # the single collective of an evaluation (sum)
-    op.finish(Q, f, stream)
+    if not multi:
+        op.finish(Q, f, stream)
+    elif reduce_spectral:
+        dist.all_reduce(qhat)
+        op.finish(Q, f, stream)
+    else:
+        op.finishPartial(Q, f, dist.get_rank() == 0, stream)
+        dist.all_reduce(Q)               # the single collective of an evaluation (sum)
 
 
 def device_view(torch, ptr, n, precision):

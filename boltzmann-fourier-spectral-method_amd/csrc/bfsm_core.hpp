@@ -278,6 +278,7 @@ struct TailLineParams {      // tail step 2: x inverse of both, Q = Re(gain) - R
     const double* f;
     double* Q;
     const cx<T>* tw;
+    int with_loss;           // 0: Q = Re(gain) only (partial result of a rank that does not own the loss term)
 };
 
 BFSM_HD int mode_of(int i, int n) { return i < n / 2 ? i : i - n; }
@@ -548,14 +549,19 @@ BFSM_HD void body_tail_line(const TailLineParams<T>& prm, Ctx& ctx) {
     cx<T> g[E], l[E];
 #pragma unroll
     for (int m = 0; m < E; ++m) g[m] = prm.tg[base + (size_t)(u + TT * m) * N * N];
-#pragma unroll
-    for (int m = 0; m < E; ++m) l[m] = prm.tl[base + (size_t)(u + TT * m) * N * N];
     fft_line<N, +1, T>(g, lds, p, u, twr, ctx);
-    fft_line<N, +1, T>(l, lds, p, u, twr, ctx);
+    if (prm.with_loss) {
 #pragma unroll
-    for (int m = 0; m < E; ++m) {
-        const size_t i = base + (size_t)(u + TT * m) * N * N;
-        prm.Q[i] = (double)g[m].x - (double)l[m].x * prm.f[i];
+        for (int m = 0; m < E; ++m) l[m] = prm.tl[base + (size_t)(u + TT * m) * N * N];
+        fft_line<N, +1, T>(l, lds, p, u, twr, ctx);
+#pragma unroll
+        for (int m = 0; m < E; ++m) {
+            const size_t i = base + (size_t)(u + TT * m) * N * N;
+            prm.Q[i] = (double)g[m].x - (double)l[m].x * prm.f[i];
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < E; ++m) prm.Q[base + (size_t)(u + TT * m) * N * N] = (double)g[m].x;
     }
 }
 

@@ -261,6 +261,14 @@ int bfsm_finish(bfsm_handle h, double* Q_dev, const double* f_dev, void* stream)
     return check_hip(h, "bfsm_finish");
 }
 
+int bfsm_finish_partial(bfsm_handle h, double* Q_dev, const double* f_dev, int with_loss, void* stream) {
+    int rc = enter(h, stream);
+    if (rc) return rc;
+    if (!f_dev || !Q_dev) return fail(h, BFSM_ERR_INVALID, "null f or Q");
+    if (h->p64) h->p64->finish(Q_dev, f_dev, with_loss != 0); else h->p32->finish(Q_dev, f_dev, with_loss != 0);
+    return check_hip(h, "bfsm_finish_partial");
+}
+
 int bfsm_collide_async(bfsm_handle h, double* Q_dev, const double* f_dev, void* stream) {
     if (!h) return BFSM_ERR_INVALID;
     if (!h->full_shard)

@@ -330,14 +330,16 @@ struct Pipeline {
     }
 
     // Loss term + final inverse transforms + combine  (CUDABoltzmannOperator.cu:193-216)
-    void finish(double* Q_dev, const double* f_dev) {
+    // with_loss = false: Q = Re IFFT(qhat) only -- the partial result a rank contributes when the caller sums Q
+    // itself (half the bytes of summing Q_hat) and another rank adds the loss term.
+    void finish(double* Q_dev, const double* f_dev, bool with_loss = true) {
         const int N = plan.N;
         const double Gc = (double)plan.G() * cbytes();
         TailInvParams<T> ta{qhat, fhat, beta2, tg, tl, tw};
-        be->mark(BFSM_K_TAIL, 4.0 * Gc);
-        be->template launch<K::TailInv, T>(N, 2, ta, N);
-        TailLineParams<T> tb{tg, tl, f_dev, Q_dev, tw};
-        be->mark(BFSM_K_TAIL, 3.0 * Gc);
+        be->mark(BFSM_K_TAIL, (with_loss ? 4.0 : 2.0) * Gc);
+        be->template launch<K::TailInv, T>(N, with_loss ? 2 : 1, ta, N);
+        TailLineParams<T> tb{tg, tl, f_dev, Q_dev, tw, with_loss ? 1 : 0};
+        be->mark(BFSM_K_TAIL, (with_loss ? 3.0 : 1.5) * Gc);
         be->template launch<K::TailLine, T>(N, 1, tb, N);
     }
 

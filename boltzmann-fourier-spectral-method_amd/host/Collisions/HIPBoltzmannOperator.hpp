@@ -44,6 +44,7 @@ public:
     // Sharded evaluation (multi-GPU): partial gain -> caller's RCCL reduce on qhatBuffer() -> finish.
     void gainPartial(const double* f_in, void* stream = nullptr);
     void finish(double* Q, const double* f_in, void* stream = nullptr);
+    void finishPartial(double* Q, const double* f_in, bool with_loss, void* stream = nullptr);
     void* qhatBuffer(size_t* n_elems, int* precision) const;
     void synchronize();
     bfsm_counters counters() const;

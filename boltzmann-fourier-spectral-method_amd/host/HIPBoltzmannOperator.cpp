@@ -51,6 +51,10 @@ void BoltzmannOperator<HIP_Backend>::finish(double* Q, const double* f_in, void*
     check(bfsm_finish(handle_, Q, f_in, stream), "finish");
 }
 
+void BoltzmannOperator<HIP_Backend>::finishPartial(double* Q, const double* f_in, bool with_loss, void* stream) {
+    check(bfsm_finish_partial(handle_, Q, f_in, with_loss ? 1 : 0, stream), "finishPartial");
+}
+
 void* BoltzmannOperator<HIP_Backend>::qhatBuffer(size_t* n_elems, int* precision) const {
     return bfsm_qhat_buffer(handle_, n_elems, precision);
 }

@@ -122,6 +122,13 @@ int bfsm_collide_async(bfsm_handle h, double* Q_dev, const double* f_dev, void* 
  */
 int bfsm_gain_partial(bfsm_handle h, const double* f_dev, void* stream);
 int bfsm_finish(bfsm_handle h, double* Q_dev, const double* f_dev, void* stream);
+/* Cheaper sharded route (half the bytes on the wire, nothing after the collective): the inverse transform is linear,
+ * so every rank transforms its OWN partial Q_gain_hat and the caller sums the real results:
+ *   bfsm_gain_partial()
+ *   bfsm_finish_partial(h, Q, f, with_loss = (rank == 0), stream)   -> Q = Re IFFT(partial Q_gain_hat) [- loss term]
+ *   <one sum all-reduce of Q (G doubles), by the caller>
+ * Exactly one rank passes with_loss != 0. */
+int bfsm_finish_partial(bfsm_handle h, double* Q_dev, const double* f_dev, int with_loss, void* stream);
 /* Device pointer to the (partial) Q_gain_hat: n_elems reals of `precision` bits (2*G, interleaved complex in the
  * library's spectral layout [lx][lz][ly]); the buffer the collective must sum in place. */
 void* bfsm_qhat_buffer(bfsm_handle h, size_t* n_elems, int* precision);

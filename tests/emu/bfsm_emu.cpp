@@ -194,7 +194,7 @@ int collide_t(const bfsm_desc* d, const double* f, double* Q, double* qhat_out) 
 // Tail only: f_hat is recomputed (gain of an empty shard), qhat_in replaces the handle's buffer (what the all-reduce
 // leaves there on a multi-GPU node), then bfsm_finish.
 template <typename T>
-int finish_t(const bfsm_desc* d, const double* f, const double* qhat_in, double* Q) {
+int finish_t(const bfsm_desc* d, const double* f, const double* qhat_in, double* Q, int with_loss) {
     EmuBackend be;
     bfsm::Pipeline<T, EmuBackend> p;
     std::string err;
@@ -205,7 +205,7 @@ int finish_t(const bfsm_desc* d, const double* f, const double* qhat_in, double*
     p.gain_partial(f);
     const size_t G = p.plan.G();
     for (size_t i = 0; i < G; ++i) p.qhat[i] = {(T)qhat_in[2 * i], (T)qhat_in[2 * i + 1]};
-    p.finish(Q, f);
+    p.finish(Q, f, with_loss != 0);
     p.destroy();
     return be.failed ? 99 : 0;
 }
@@ -246,11 +246,11 @@ int bfsm_emu_collide(const bfsm_desc* d, const double* f, double* Q, double* qha
 }
 
 // Emulated bfsm_finish on a caller-provided (already reduced) Q_gain_hat in the spectral layout.
-int bfsm_emu_finish(const bfsm_desc* d, const double* f, const double* qhat_in, double* Q) {
+int bfsm_emu_finish(const bfsm_desc* d, const double* f, const double* qhat_in, double* Q, int with_loss) {
     std::string err;
     int rc = bfsm::validate_desc(*d, err);
     if (rc) return rc;
-    return d->precision == BFSM_F64 ? emu::finish_t<double>(d, f, qhat_in, Q) : emu::finish_t<float>(d, f, qhat_in, Q);
+    return d->precision == BFSM_F64 ? emu::finish_t<double>(d, f, qhat_in, Q, with_loss) : emu::finish_t<float>(d, f, qhat_in, Q, with_loss);
 }
 
 // Emulated bfsm_fft3d; data = batch*G interleaved complex doubles (narrowed to float when precision == 32).

@@ -106,20 +106,24 @@ class EmuOperator:
             raise RuntimeError(f"bfsm_emu_collide rc={rc}")
         self.qhat.copy_(torch.from_numpy(qh))
 
-    def finish(self, Q, f, stream=0):
+    def finishPartial(self, Q, f, with_loss, stream=0):
+        self.finish(Q, f, stream, with_loss=with_loss)
+
+    def finish(self, Q, f, stream=0, with_loss=True):
         import torch
         L = lib()
         dp = ctypes.POINTER(ctypes.c_double)
         if not hasattr(L.bfsm_emu_finish, "_typed"):
             from bfsm import capi
-            L.bfsm_emu_finish.argtypes = [ctypes.POINTER(capi.Desc), dp, dp, dp]
+            L.bfsm_emu_finish.argtypes = [ctypes.POINTER(capi.Desc), dp, dp, dp, ctypes.c_int]
             L.bfsm_emu_finish.restype = ctypes.c_int
             L.bfsm_emu_finish._typed = True
         d, keep = make_desc(self.nv, self.gl, self.sph, *self.args, 64, self.dir_range, self.max_chunk)
         fh = np.ascontiguousarray(f.numpy(), dtype=np.float64)
         qh = np.ascontiguousarray(self.qhat.numpy())
         out = np.empty(self.nv ** 3)
-        rc = L.bfsm_emu_finish(ctypes.byref(d), fh.ctypes.data_as(dp), qh.ctypes.data_as(dp), out.ctypes.data_as(dp))
+        rc = L.bfsm_emu_finish(ctypes.byref(d), fh.ctypes.data_as(dp), qh.ctypes.data_as(dp), out.ctypes.data_as(dp),
+                               1 if with_loss else 0)
         if rc:
             raise RuntimeError(f"bfsm_emu_finish rc={rc}")
         Q.copy_(torch.from_numpy(out))

@@ -278,3 +278,26 @@ def test_exact_reductions_full_size_and_shards(torch_cuda):
     l1, l2, linf = bfsm.error_norms(got, q_exact, dv)
     assert abs(l2 - row["L2"]) <= 1e-10 and l2 == pytest.approx(row["L2"], rel=6e-9)
     assert linf == pytest.approx(row["Linf"], rel=6e-9)
+
+
+def test_sharded_real_reduce_route(torch_cuda, oracle):
+    """Default multi-GPU route: every shard inverse-transforms its own partial Q_gain_hat (bfsm_finish_partial, loss
+    term on shard 0 only) and the real results are summed -- what the all-reduce of Q does on a multi-GPU node."""
+    import bfsm
+    torch = torch_cuda
+    nv, n_gl, n_sph = 32, 4, 12
+    f_h = bfsm.perturbed_input(bfsm.bkw_solution(nv)[0])
+    f = torch.from_numpy(f_h).cuda()
+    ref = _oracle(oracle, f_h, n_gl, n_sph)
+    for P in (2, 5):
+        total = torch.zeros_like(f)
+        for r in range(P):
+            op = _make(bfsm, nv, n_gl, n_sph, shard=bfsm.shard_range(n_gl * n_sph, r, P))
+            Qr = torch.empty_like(f)
+            op.gainPartial(f)
+            op.finishPartial(Qr, f, r == 0)
+            op.synchronize()
+            total += Qr
+            op.destroy()
+        got = total.cpu().numpy()
+        assert np.abs(got - ref).max() <= TOL64 * np.abs(ref).max()
