@@ -12,9 +12,10 @@ from .operator import HIPBoltzmannOperator, shard_range
 from .sharded import device_view, sharded_step
 from .quadrature import GaussLegendreQuadrature, SphericalDesign
 from .bkw import bkw_solution, error_norms, reference_constants, perturbed_input
+from .relax import relax_bkw, ssp_rk3_step
 
 __all__ = [
     "BFSM_F32", "BFSM_F64", "BFSM_FLAG_PROFILE", "BFSM_FLAG_EXACT_REDUCTIONS", "KERNEL_NAMES", "BfsmError", "Counters", "Desc", "lib_path",
     "load_library", "HIPBoltzmannOperator", "shard_range", "sharded_step", "device_view", "GaussLegendreQuadrature", "SphericalDesign",
-    "bkw_solution", "error_norms", "reference_constants", "perturbed_input",
+    "bkw_solution", "error_norms", "reference_constants", "perturbed_input", "relax_bkw", "ssp_rk3_step",
 ]

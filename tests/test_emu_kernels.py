@@ -160,3 +160,17 @@ def test_exact_reductions_sharded(oracle):
         _, qh = E.collide(f, gl, sph, GAMMA, B_GAMMA, L, 64, dir_range=rng_, want_Q=False, flags=EXACT)
         parts = parts + qh
     assert np.abs(parts - whole).max() <= 1e-12 * np.abs(whole).max()
+
+
+@pytest.mark.parametrize("gamma,b_gamma", [(1.0, 1.0 / (4.0 * np.pi)), (2.0, 0.3), (-0.5, 0.1)])
+def test_general_collision_kernels(oracle, gamma, b_gamma):
+    """gamma != 0 (hard spheres gamma = 1, ...) only changes the tabulated weights rho^(gamma+2)
+    (FFTWBoltzmannOperator.cpp:252,290-293); the operator is checked against the oracle for those too."""
+    f, _, L, _ = oracle.bkw(16)
+    f = oracle.perturbed_input(f)
+    gl = oracle.gauss_legendre(3, 0.0, R)
+    sph = oracle.spherical_design(12)
+    Qo = oracle.collide(f, gl, sph, gamma, b_gamma, L)
+    for flags in (0, EXACT):
+        Q, _ = E.collide(f, gl, sph, gamma, b_gamma, L, 64, flags=flags)
+        assert np.abs(Q - Qo).max() <= 1e-12 * np.abs(Qo).max()

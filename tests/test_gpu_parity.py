@@ -23,8 +23,11 @@ def torch_cuda():
     return torch
 
 
-def _make(bfsm, nv, n_gl, n_sph, precision=64, shard=None, max_chunk=0, profile=False, exact=False):
-    c = bfsm.reference_constants()
+def _make(bfsm, nv, n_gl, n_sph, precision=64, shard=None, max_chunk=0, profile=False, exact=False, gamma=None,
+          b_gamma=None):
+    c = dict(bfsm.reference_constants())
+    if gamma is not None:
+        c["gamma"], c["b_gamma"] = gamma, b_gamma
     L = c["L"]
     op = bfsm.HIPBoltzmannOperator(bfsm.GaussLegendreQuadrature(n_gl, 0.0, c["R"]), bfsm.SphericalDesign(n_sph),
                                    nv, nv, nv, c["gamma"], c["b_gamma"], L)
@@ -301,3 +304,40 @@ def test_sharded_real_reduce_route(torch_cuda, oracle):
             op.destroy()
         got = total.cpu().numpy()
         assert np.abs(got - ref).max() <= TOL64 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("gamma,b_gamma", [(1.0, 1.0 / (4.0 * np.pi)), (2.0, 0.3)])
+def test_general_collision_kernels(torch_cuda, oracle, gamma, b_gamma):
+    """hard spheres (gamma = 1) and gamma = 2 against the oracle, both modes, plus the discrete
+    conservation sanity check that replaces the missing analytic answer: mass defect of Q is at truncation level."""
+    import bfsm
+    nv, n_gl, n_sph = 32, 8, 32
+    c = bfsm.reference_constants()
+    f_h = bfsm.perturbed_input(bfsm.bkw_solution(nv)[0])
+    ref = oracle.collide(f_h, oracle.gauss_legendre(n_gl, 0.0, c["R"]), oracle.spherical_design(n_sph), gamma, b_gamma, c["L"])
+    for exact in (False, True):
+        op = _make(bfsm, nv, n_gl, n_sph, exact=exact, gamma=gamma, b_gamma=b_gamma)
+        got = _collide(torch_cuda, op, f_h)
+        assert np.abs(got - ref).max() <= TOL64 * np.abs(ref).max()
+        op.destroy()
+    dv = 2 * c["L"] / nv
+    assert abs(got.sum()) * dv ** 3 <= 5e-2 * np.abs(got).sum() * dv ** 3      # N=32, 8 radial nodes: truncation level
+
+
+def test_bkw_relaxation_time_stepping(torch_cuda):
+    """SURVEY 8(f3), caller side: SSP-RK3 on d f/dt = Q(f,f) with f resident on the device, from the BKW state at
+    t = 5.5 to the reference's t = 6.5.  The result must track the exact BKW solution to the spectral accuracy of the
+    grid, halve-dt must not change it (time error negligible), mass must be conserved to truncation level and the
+    entropy must decrease towards the exact value."""
+    import bfsm
+    torch = torch_cuda
+    nv, n_gl, n_sph = 32, 16, 32
+    op = _make(bfsm, nv, n_gl, n_sph, exact=True)
+    a = bfsm.relax_bkw(op, nv, 5.5, 6.5, 10, torch)
+    b = bfsm.relax_bkw(op, nv, 5.5, 6.5, 20, torch)
+    op.destroy()
+    assert a["l2_error"] < 2e-4 and b["l2_error"] < 2e-4              # f ~ 1e-2 .. 1e-1 at the origin
+    assert abs(a["l2_error"] - b["l2_error"]) < 1e-6                   # RK3 error << spectral error
+    assert a["mass_drift"] < 5e-4 and a["energy_drift"] < 5e-3
+    assert a["entropy_end"] < a["entropy_start"]
+    assert abs(a["entropy_end"] - a["entropy_exact_end"]) < 1e-3 * abs(a["entropy_exact_end"])
