@@ -12,7 +12,7 @@ K_COUNT = len(KERNEL_NAMES)
 
 # every symbol include/bfsm.h declares (checked by tests/test_capi_symbols.py)
 EXPORTED_SYMBOLS = (
-    "bfsm_create", "bfsm_collide", "bfsm_collide_async", "bfsm_gain_partial", "bfsm_finish", "bfsm_finish_partial",
+    "bfsm_create", "bfsm_collide", "bfsm_collide_async", "bfsm_collide_batch", "bfsm_collide_batch_async", "bfsm_gain_partial", "bfsm_finish", "bfsm_finish_partial",
     "bfsm_qhat_buffer",
     "bfsm_synchronize", "bfsm_fft3d", "bfsm_get_counters", "bfsm_destroy", "bfsm_last_error", "bfsm_backend_name",
     "bfsm_version",
@@ -30,7 +30,7 @@ class Desc(ctypes.Structure):
         ("gamma", ctypes.c_double), ("b_gamma", ctypes.c_double), ("L", ctypes.c_double),
         ("precision", ctypes.c_int), ("device", ctypes.c_int),
         ("dir_begin", ctypes.c_longlong), ("dir_end", ctypes.c_longlong),
-        ("max_chunk", ctypes.c_int), ("flags", ctypes.c_int),
+        ("max_chunk", ctypes.c_int), ("flags", ctypes.c_int), ("max_batch", ctypes.c_int),
     ]
 
 
@@ -77,6 +77,10 @@ def load_library(path=None):
     L.bfsm_collide.restype = ctypes.c_int
     L.bfsm_collide_async.argtypes = [vp, vp, vp, vp]
     L.bfsm_collide_async.restype = ctypes.c_int
+    L.bfsm_collide_batch.argtypes = [vp, vp, vp, ctypes.c_int]
+    L.bfsm_collide_batch.restype = ctypes.c_int
+    L.bfsm_collide_batch_async.argtypes = [vp, vp, vp, ctypes.c_int, vp]
+    L.bfsm_collide_batch_async.restype = ctypes.c_int
     L.bfsm_gain_partial.argtypes = [vp, vp, vp]
     L.bfsm_gain_partial.restype = ctypes.c_int
     L.bfsm_finish.argtypes = [vp, vp, vp, vp]

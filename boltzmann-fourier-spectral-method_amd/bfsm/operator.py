@@ -30,6 +30,7 @@ class HIPBoltzmannOperator:
         self._dir_range = (0, 0)
         self._max_chunk = 0
         self._flags = 0
+        self._max_batch = 0
         self._h = None
         self._lib = None
 
@@ -45,6 +46,10 @@ class HIPBoltzmannOperator:
 
     def setMaxChunk(self, n):
         self._max_chunk = int(n)
+
+    def setMaxBatch(self, n):
+        """Distributions per computeCollisionBatch call (scratch scales with it)."""
+        self._max_batch = int(n)
 
     def setProfiling(self, on=True):
         self._flags = (self._flags | capi.BFSM_FLAG_PROFILE) if on else (self._flags & ~capi.BFSM_FLAG_PROFILE)
@@ -71,7 +76,7 @@ class HIPBoltzmannOperator:
         d = capi.Desc(self.Nvx, self.Nvy, self.Nvz, gl.getNumberOfPoints(), sp.getNumberOfPoints(),
                       *[a.ctypes.data_as(dp) for a in keep],
                       self.gamma, self.b_gamma, self.L, self._precision, self._device,
-                      self._dir_range[0], self._dir_range[1], self._max_chunk, self._flags)
+                      self._dir_range[0], self._dir_range[1], self._max_chunk, self._flags, self._max_batch)
         h = ctypes.c_void_p()
         rc = self._lib.bfsm_create(ctypes.byref(d), ctypes.byref(h))
         if rc != capi.BFSM_OK:
@@ -98,6 +103,21 @@ class HIPBoltzmannOperator:
     def computeCollisionAsync(self, Q, f_in, stream=0):
         self._require(f_in, Q)
         self._check(self._lib.bfsm_collide_async(self._h, _ptr(Q), _ptr(f_in), ctypes.c_void_p(stream)))
+
+    def computeCollisionBatch(self, Q, f_in, n_batch, stream=None):
+        """n_batch distributions [n_batch][Nvx*Nvy*Nvz] in one set of launches.  Blocking when
+        stream is None, otherwise enqueued on that stream."""
+        if self._h is None:
+            raise RuntimeError("initialize() has not been called")
+        G = self.Nvx * self.Nvy * self.Nvz
+        for t in (f_in, Q):
+            if not (t.is_cuda and t.element_size() == 8 and t.is_contiguous() and t.numel() == n_batch * G):
+                raise ValueError("f and Q must be contiguous float64 CUDA tensors with n_batch*Nvx*Nvy*Nvz elements")
+        if stream is None:
+            self._check(self._lib.bfsm_collide_batch(self._h, _ptr(Q), _ptr(f_in), int(n_batch)))
+        else:
+            self._check(self._lib.bfsm_collide_batch_async(self._h, _ptr(Q), _ptr(f_in), int(n_batch),
+                                                           ctypes.c_void_p(stream)))
 
     def gainPartial(self, f_in, stream=0):
         self._require(f_in)

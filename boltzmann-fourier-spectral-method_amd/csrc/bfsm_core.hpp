@@ -210,6 +210,7 @@ struct GainInvParams {       // KA
     long long dir0;          // global index of the chunk's first direction (b = r*M_sph + s)
     int n_dir;               // directions in this chunk
     int per_group;           // directions handled by one workgroup (blockIdx.y)
+    size_t a_bstride;        // elements between consecutive batch members (blockIdx.z) in a1 / a2
 };
 
 template <typename T>
@@ -217,6 +218,7 @@ struct GainLineParams {      // KB
     cx<T>* a1;               // in: A1', out: P' (in place)
     const cx<T>* a2;
     const cx<T>* tw;
+    size_t a_bstride;        // batch stride (elements) of a1 / a2
 };
 
 // One accumulating workgroup column of KC: a run of directions that all share the radial node r, so that beta1
@@ -237,6 +239,8 @@ struct GainFwdParams {       // KC
     const cx<T>* tw;
     long long dir0;          // shard-local index of the chunk's first direction
     int seg0;                // first segment of this chunk (== its first slab)
+    size_t p_bstride;        // batch strides (elements) of p and slab
+    size_t slab_bstride;
 };
 
 template <typename T>
@@ -247,6 +251,7 @@ struct ReduceParams {        // Q_hat[l] = sum_segments beta1[r(seg)][|l|^2] * s
     const Segment* segs;
     int n_segs;
     int n2stride;            // 3 (N/2)^2 + 1
+    size_t slab_bstride;     // batch stride (elements) of slab; qhat is [batch][G]
 };
 
 template <typename T>
@@ -259,6 +264,8 @@ struct GainLineAccParams {   // KB', exact-reduction mode: sum over the directio
     const cx<T>* tw;
     long long dir0;          // shard-local index of the chunk's first direction
     int seg0;                // first segment of this chunk
+    size_t a_bstride;        // batch strides (elements) of a1 / a2 and of pseg
+    size_t pseg_bstride;
 };
 
 template <typename T>
@@ -294,15 +301,16 @@ BFSM_HD void body_tile_fwd_real(const TileFwdRealParams<T>& prm, Ctx& ctx) {
     constexpr int E = Wg<N>::E, TT = Wg<N>::T;
     const int tid = ctx.tid(), p = tid % N, u = ctx.uniform(tid / N, N);
     const int x = ctx.bx();
+    const size_t boff = (size_t)ctx.by() * N * N * N;      // batch member
     cx<T>* lds = ctx.template lds<cx<T>>();
     cx<T> twr[E - 1];
     load_twiddles<N, T>(twr, prm.tw, u, ctx);
     cx<T> v[E];
-    const double* src = prm.f + (size_t)x * N * N;
+    const double* src = prm.f + boff + (size_t)x * N * N;
 #pragma unroll
     for (int m = 0; m < E; ++m) v[m] = {(T)src[(u + TT * m) * N + p], (T)0};
     fft_tile<N, -1, T>(v, lds, p, u, twr, ctx);
-    cx<T>* dst = prm.out + (size_t)x * N * N;
+    cx<T>* dst = prm.out + boff + (size_t)x * N * N;
 #pragma unroll
     for (int m = 0; m < E; ++m) dst[(u + TT * m) * N + p] = v[m];
 }
@@ -355,7 +363,8 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
     cx<T> twr[E - 1];
     load_twiddles<N, T>(twr, prm.tw, u, ctx);
     cx<T> fh[E];
-    const cx<T>* src = prm.fhat + (size_t)lxi * N * N;
+    const size_t bz = (size_t)ctx.bz();
+    const cx<T>* src = prm.fhat + bz * N * N * N + (size_t)lxi * N * N;
 #pragma unroll
     for (int m = 0; m < E; ++m) fh[m] = src[(u + TT * m) * N + p];  // [lz = u + T m][ly = p]
     const int d_begin = ctx.by() * prm.per_group;
@@ -381,7 +390,7 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
             v[m] = conj ? cmulc(fh[m], ph) : cmul(fh[m], ph);   // conj(alpha1) f_hat / G  :  alpha1 f_hat / G
         }
         fft_tile<N, +1, T>(v, lds, p, u, twr, ctx);
-        cx<T>* dst = (conj ? prm.a2 : prm.a1) + ((size_t)d * N + lxi) * N * N;
+        cx<T>* dst = (conj ? prm.a2 : prm.a1) + bz * prm.a_bstride + ((size_t)d * N + lxi) * N * N;
 #pragma unroll
         for (int m = 0; m < E; ++m) ctx.st_stream(dst + (size_t)(u + TT * m) * N + p, v[m]);  // [y = u + T m][z = p]
     }
@@ -393,7 +402,7 @@ template <int N, typename T, class Ctx>
 BFSM_HD void body_gain_line(const GainLineParams<T>& prm, Ctx& ctx) {
     constexpr int E = Wg<N>::E, TT = Wg<N>::T;
     const int tid = ctx.tid(), p = tid % N, u = ctx.uniform(tid / N, N);
-    const size_t base = (size_t)ctx.by() * N * N * N + (size_t)ctx.bx() * N + p;
+    const size_t base = (size_t)ctx.bz() * prm.a_bstride + (size_t)ctx.by() * N * N * N + (size_t)ctx.bx() * N + p;
     cx<T>* lds = ctx.template lds<cx<T>>();
     cx<T> twr[E - 1];
     load_twiddles<N, T>(twr, prm.tw, u, ctx);
@@ -428,7 +437,7 @@ BFSM_HD void body_gain_line_acc(const GainLineAccParams<T>& prm, Ctx& ctx) {
 #pragma unroll
     for (int m = 0; m < E; ++m) acc[m] = {(T)0, (T)0};
     for (int d = seg.d0; d < seg.d0 + seg.n; ++d) {
-        const size_t base = (size_t)d * N * N * N + row;
+        const size_t base = (size_t)ctx.bz() * prm.a_bstride + (size_t)d * N * N * N + row;
         cx<T> a[E], b[E];
 #pragma unroll
         for (int m = 0; m < E; ++m) a[m] = ctx.ld_stream(prm.a1 + base + (size_t)(u + TT * m) * N * N);
@@ -445,7 +454,7 @@ BFSM_HD void body_gain_line_acc(const GainLineAccParams<T>& prm, Ctx& ctx) {
         }
     }
     fft_line<N, -1, T>(acc, lds, p, u, twr, ctx);
-    const size_t obase = (size_t)(prm.seg0 + ctx.by()) * N * N * N + row;
+    const size_t obase = (size_t)ctx.bz() * prm.pseg_bstride + (size_t)(prm.seg0 + ctx.by()) * N * N * N + row;
 #pragma unroll
     for (int m = 0; m < E; ++m) prm.pseg[obase + (size_t)(u + TT * m) * N * N] = acc[m];
 }
@@ -466,7 +475,7 @@ BFSM_HD void body_gain_fwd(const GainFwdParams<T>& prm, Ctx& ctx) {
     for (int m = 0; m < E; ++m) acc[m] = {(T)0, (T)0};
     const Segment seg = prm.segs[prm.seg0 + ctx.by()];
     for (int d = seg.d0; d < seg.d0 + seg.n; ++d) {
-        const cx<T>* src = prm.p + ((size_t)d * N + x) * N * N;
+        const cx<T>* src = prm.p + (size_t)ctx.bz() * prm.p_bstride + ((size_t)d * N + x) * N * N;
         cx<T> v[E];
 #pragma unroll
         for (int m = 0; m < E; ++m) v[m] = ctx.ld_stream(src + (u + TT * m) * N + p);  // [y = u + T m][z = p]
@@ -478,7 +487,7 @@ BFSM_HD void body_gain_fwd(const GainFwdParams<T>& prm, Ctx& ctx) {
             acc[m].y += w * v[m].y;
         }
     }
-    cx<T>* dst = prm.slab + ((size_t)(prm.seg0 + ctx.by()) * N + x) * N * N;
+    cx<T>* dst = prm.slab + (size_t)ctx.bz() * prm.slab_bstride + ((size_t)(prm.seg0 + ctx.by()) * N + x) * N * N;
 #pragma unroll
     for (int m = 0; m < E; ++m) dst[(u + TT * m) * N + p] = acc[m];   // [lz = u + T m][ly = p]
 }
@@ -495,12 +504,12 @@ BFSM_HD void body_reduce(const ReduceParams<T>& prm, Ctx& ctx) {
     const int n2 = mx * mx + my * my + mz * mz;
     cx<T> q = {(T)0, (T)0};
     for (int c = 0; c < prm.n_segs; ++c) {
-        const cx<T> t = prm.slab[(size_t)c * G + idx];
+        const cx<T> t = prm.slab[(size_t)ctx.by() * prm.slab_bstride + (size_t)c * G + idx];
         const T b1 = prm.beta1[(size_t)prm.segs[c].r * prm.n2stride + n2];
         q.x += b1 * t.x;
         q.y += b1 * t.y;
     }
-    prm.qhat[idx] = q;
+    prm.qhat[(size_t)ctx.by() * G + idx] = q;
 }
 
 // Tail 1.  grid = (N planes lx, 2).  y==0: Q_hat plane; y==1: beta2 * f_hat / G
@@ -516,7 +525,7 @@ BFSM_HD void body_tail_inv(const TailInvParams<T>& prm, Ctx& ctx) {
     cx<T> twr[E - 1];
     load_twiddles<N, T>(twr, prm.tw, u, ctx);
     cx<T> v[E];
-    const size_t pbase = (size_t)lxi * N * N;
+    const size_t pbase = (size_t)ctx.bz() * N * N * N + (size_t)lxi * N * N;
     if (!loss) {
 #pragma unroll
         for (int m = 0; m < E; ++m) v[m] = prm.qhat[pbase + (u + TT * m) * N + p];
@@ -542,7 +551,7 @@ template <int N, typename T, class Ctx>
 BFSM_HD void body_tail_line(const TailLineParams<T>& prm, Ctx& ctx) {
     constexpr int E = Wg<N>::E, TT = Wg<N>::T;
     const int tid = ctx.tid(), p = tid % N, u = ctx.uniform(tid / N, N);
-    const size_t base = (size_t)ctx.bx() * N + p;
+    const size_t base = (size_t)ctx.by() * N * N * N + (size_t)ctx.bx() * N + p;
     cx<T>* lds = ctx.template lds<cx<T>>();
     cx<T> twr[E - 1];
     load_twiddles<N, T>(twr, prm.tw, u, ctx);

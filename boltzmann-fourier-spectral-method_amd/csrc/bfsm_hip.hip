@@ -18,6 +18,7 @@ struct DevCtx {
     __device__ __forceinline__ int nthreads() const { return (int)blockDim.x; }
     __device__ __forceinline__ int bx() const { return (int)blockIdx.x; }
     __device__ __forceinline__ int by() const { return (int)blockIdx.y; }
+    __device__ __forceinline__ int bz() const { return (int)blockIdx.z; }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
     // value known to be equal across a wave when a row of n lanes covers whole waves: make it an SGPR so the
     // twiddle / phase-table loads that depend on it become scalar loads
@@ -122,7 +123,7 @@ struct HipBackend {
     void mark(int kind, double bytes) { pend_kind = kind; pend_bytes = bytes; }
 
     template <K kind, int N, typename T, class P>
-    void launch_n(int gx, int gy, const P& prm) {
+    void launch_n(int gx, int gy, int gz, const P& prm) {
         constexpr int threads = kernel_threads<kind, N>();
         constexpr size_t lds = kind == K::Reduce ? 0 : (size_t)Wg<N>::LDS_ELEMS * sizeof(cx<T>);
         auto fn = bfsm_kernel<kind, N, T, P>;
@@ -134,21 +135,21 @@ struct HipBackend {
         Rec rec{pend_kind, pend_bytes, nullptr, nullptr};
         const bool timed = profile && pend_kind >= 0;
         if (timed) { rec.e0 = next_event(); rec.e1 = next_event(); BFSM_NOTE(hipEventRecord(rec.e0, stream)); }
-        hipLaunchKernelGGL(fn, dim3((unsigned)gx, (unsigned)gy, 1), dim3(threads, 1, 1), lds, stream, prm);
+        hipLaunchKernelGGL(fn, dim3((unsigned)gx, (unsigned)gy, (unsigned)gz), dim3(threads, 1, 1), lds, stream, prm);
         BFSM_NOTE(hipGetLastError());
         if (timed) { BFSM_NOTE(hipEventRecord(rec.e1, stream)); recs.push_back(rec); }
         pend_kind = -1;
     }
 
     template <K kind, typename T, class P>
-    void launch(int gx, int gy, const P& prm, int N) {
-        if (gx <= 0 || gy <= 0) return;
+    void launch(int gx, int gy, int gz, const P& prm, int N) {
+        if (gx <= 0 || gy <= 0 || gz <= 0) return;
         switch (N) {
-            case 16: launch_n<kind, 16, T>(gx, gy, prm); break;
-            case 32: launch_n<kind, 32, T>(gx, gy, prm); break;
-            case 64: launch_n<kind, 64, T>(gx, gy, prm); break;
+            case 16: launch_n<kind, 16, T>(gx, gy, gz, prm); break;
+            case 32: launch_n<kind, 32, T>(gx, gy, gz, prm); break;
+            case 64: launch_n<kind, 64, T>(gx, gy, gz, prm); break;
             case 128:
-                if constexpr (sizeof(T) == 4) launch_n<kind, 128, T>(gx, gy, prm);
+                if constexpr (sizeof(T) == 4) launch_n<kind, 128, T>(gx, gy, gz, prm);
                 break;
             default: break;
         }
@@ -267,6 +268,26 @@ int bfsm_finish_partial(bfsm_handle h, double* Q_dev, const double* f_dev, int w
     if (!f_dev || !Q_dev) return fail(h, BFSM_ERR_INVALID, "null f or Q");
     if (h->p64) h->p64->finish(Q_dev, f_dev, with_loss != 0); else h->p32->finish(Q_dev, f_dev, with_loss != 0);
     return check_hip(h, "bfsm_finish_partial");
+}
+
+int bfsm_collide_batch_async(bfsm_handle h, double* Q_dev, const double* f_dev, int n_batch, void* stream) {
+    int rc = enter(h, stream);
+    if (rc) return rc;
+    if (!f_dev || !Q_dev) return fail(h, BFSM_ERR_INVALID, "null f or Q");
+    if (!h->full_shard) return fail(h, BFSM_ERR_INVALID, "batched evaluation needs a handle that owns all directions");
+    const int cap = h->p64 ? h->p64->max_batch : h->p32->max_batch;
+    if (n_batch < 1 || n_batch > cap)
+        return fail(h, BFSM_ERR_INVALID, "n_batch must be in [1, max_batch of the descriptor]");
+    h->be.begin_eval();
+    if (h->p64) { h->p64->gain_partial(f_dev, n_batch); h->p64->finish(Q_dev, f_dev, true, n_batch); }
+    else { h->p32->gain_partial(f_dev, n_batch); h->p32->finish(Q_dev, f_dev, true, n_batch); }
+    return check_hip(h, "bfsm_collide_batch");
+}
+
+int bfsm_collide_batch(bfsm_handle h, double* Q_dev, const double* f_dev, int n_batch) {
+    int rc = bfsm_collide_batch_async(h, Q_dev, f_dev, n_batch, nullptr);
+    if (rc) return rc;
+    return bfsm_synchronize(h);
 }
 
 int bfsm_collide_async(bfsm_handle h, double* Q_dev, const double* f_dev, void* stream) {

@@ -73,6 +73,7 @@ inline int validate_desc(const bfsm_desc& d, std::string& err) {
         err = "direction shard out of range"; return BFSM_ERR_INVALID;
     }
     if (d.max_chunk < 0) { err = "max_chunk must be >= 0"; return BFSM_ERR_INVALID; }
+    if (d.max_batch < 0 || d.max_batch > 65535) { err = "max_batch must be in [0, 65535]"; return BFSM_ERR_INVALID; }
     return BFSM_OK;
 }
 
@@ -212,7 +213,7 @@ enum class K { TileFwdReal, LineFwd, LineInv, TileFwd, TileInv, GainInv, GainLin
 
 // Device-resident state of one handle.  `Backend` supplies:
 //   void* alloc(size_t), void release(void*), void upload(void* dst, const void* src, size_t), void zero(void*, size_t)
-//   template <K kind, typename T, class P> void launch(int grid_x, int grid_y, const P& params, int N)
+//   template <K kind, typename T, class P> void launch(int grid_x, int grid_y, int grid_z, const P& params, int N)
 //   void mark(int kind, double alg_bytes)              -- accounting tag of the next launch (kind < 0: untracked)
 template <typename T, class Backend>
 struct Pipeline {
@@ -249,28 +250,34 @@ struct Pipeline {
         return true;
     }
 
+    int max_batch = 1;       // distributions evaluated per call; scratch scales with it
+    size_t cap = 1;          // directions resident at once (largest chunk)
+
     int init(const bfsm_desc& d, Backend* backend, std::string& err) {
         be = backend;
         plan = make_plan(d);
         HostTables<T> t = build_tables<T>(d, plan);
         const size_t G = plan.G();
-        const size_t cap = (size_t)(plan.largest_chunk > 0 ? plan.largest_chunk : 1);
+        cap = (size_t)(plan.largest_chunk > 0 ? plan.largest_chunk : 1);
+        max_batch = d.max_batch > 1 ? d.max_batch : 1;
+        const size_t nb = (size_t)max_batch;
         slab_count = plan.segs.size();
+        const size_t nslab = slab_count ? slab_count : 1;
         bool ok = true;
-        ok = ok && (fhat = (cx<T>*)be->alloc(G * sizeof(cx<T>)));
-        ok = ok && (tg = (cx<T>*)be->alloc(G * sizeof(cx<T>)));
-        ok = ok && (tl = (cx<T>*)be->alloc(G * sizeof(cx<T>)));
-        ok = ok && (qhat = (cx<T>*)be->alloc(G * sizeof(cx<T>)));
-        ok = ok && (a1 = (cx<T>*)be->alloc(cap * G * sizeof(cx<T>)));
-        ok = ok && (a2 = (cx<T>*)be->alloc(cap * G * sizeof(cx<T>)));
-        ok = ok && (slab = (cx<T>*)be->alloc((slab_count ? slab_count : 1) * G * sizeof(cx<T>)));
+        ok = ok && (fhat = (cx<T>*)be->alloc(nb * G * sizeof(cx<T>)));
+        ok = ok && (tg = (cx<T>*)be->alloc(nb * G * sizeof(cx<T>)));
+        ok = ok && (tl = (cx<T>*)be->alloc(nb * G * sizeof(cx<T>)));
+        ok = ok && (qhat = (cx<T>*)be->alloc(nb * G * sizeof(cx<T>)));
+        ok = ok && (a1 = (cx<T>*)be->alloc(nb * cap * G * sizeof(cx<T>)));
+        ok = ok && (a2 = (cx<T>*)be->alloc(nb * cap * G * sizeof(cx<T>)));
+        ok = ok && (slab = (cx<T>*)be->alloc(nb * nslab * G * sizeof(cx<T>)));
         ok = ok && dev_copy(tw, t.tw) && dev_copy(phx, t.phx) && dev_copy(phy, t.phy) && dev_copy(phz, t.phz);
         ok = ok && dev_copy(dirw, t.dirw) && dev_copy(beta1, t.beta1) && dev_copy(beta2, t.beta2) && dev_copy(segs, plan.segs);
         if (ok && plan.exact_reductions) {
             std::vector<Segment> unit(plan.segs.size());
             for (size_t i = 0; i < unit.size(); ++i) unit[i] = Segment{(int)i, 1, plan.segs[i].r, 0};
             std::vector<T> one(unit.size() ? unit.size() : 1, (T)1);
-            ok = ok && (pseg = (cx<T>*)be->alloc((slab_count ? slab_count : 1) * G * sizeof(cx<T>)));
+            ok = ok && (pseg = (cx<T>*)be->alloc(nb * nslab * G * sizeof(cx<T>)));
             ok = ok && dev_copy(segs_unit, unit) && dev_copy(ones, one);
         }
         if (!ok) { err = "device allocation failed"; return BFSM_ERR_NOMEM; }
@@ -290,57 +297,61 @@ struct Pipeline {
     double cbytes() const { return (double)sizeof(cx<T>); }
 
     // f_hat = FFT(f), then the gain term of this shard into qhat (partial Q_gain_hat, spectral layout).
-    void gain_partial(const double* f_dev) {
+    // nb distributions f_dev[nb][G] are processed by the same launches (grid.z / grid.y = batch member); all
+    // per-distribution buffers are [nb][...].
+    void gain_partial(const double* f_dev, int nb = 1) {
         const int N = plan.N;
-        const double Gc = (double)plan.G() * cbytes();
+        const double Gc = (double)plan.G() * cbytes() * nb;
+        const size_t G = plan.G();
+        const size_t a_bs = cap * G, s_bs = (slab_count ? slab_count : 1) * G;
         {   // F1: f_hat  (CUDABoltzmannOperator.cu:133-140)
             TileFwdRealParams<T> pa{f_dev, tg, tw};
             be->mark(BFSM_K_FFT_F, 1.5 * Gc);
-            be->template launch<K::TileFwdReal, T>(N, 1, pa, N);
+            be->template launch<K::TileFwdReal, T>(N, nb, 1, pa, N);
             LineParams<T> pb{tg, fhat, tw};
             be->mark(BFSM_K_FFT_F, 2.0 * Gc);
-            be->template launch<K::LineFwd, T>(N, 1, pb, N);
+            be->template launch<K::LineFwd, T>(N, nb, 1, pb, N);
         }
         for (const Chunk& c : plan.chunks) {
-            GainInvParams<T> ka{fhat, a1, a2, phx, phy, phz, tw, c.dir0, c.n, c.per_group};
+            GainInvParams<T> ka{fhat, a1, a2, phx, phy, phz, tw, c.dir0, c.n, c.per_group, a_bs};
             const int ga = (c.n + c.per_group - 1) / c.per_group;
             be->mark(BFSM_K_GAIN_INV, 2.0 * c.n * Gc);
-            be->template launch<K::GainInv, T>(N, ga, ka, N);
+            be->template launch<K::GainInv, T>(N, ga, nb, ka, N);
             if (!plan.exact_reductions) {
-                GainLineParams<T> kb{a1, a2, tw};
+                GainLineParams<T> kb{a1, a2, tw, a_bs};
                 be->mark(BFSM_K_GAIN_LINE, 3.0 * c.n * Gc);
-                be->template launch<K::GainLine, T>(N, c.n, kb, N);
-                GainFwdParams<T> kc{a1, slab, dirw, segs, tw, c.dir0, c.seg0};
+                be->template launch<K::GainLine, T>(N, c.n, nb, kb, N);
+                GainFwdParams<T> kc{a1, slab, dirw, segs, tw, c.dir0, c.seg0, a_bs, s_bs};
                 be->mark(BFSM_K_GAIN_FWD, 1.0 * c.n * Gc);
-                be->template launch<K::GainFwd, T>(N, c.n_seg, kc, N);
+                be->template launch<K::GainFwd, T>(N, c.n_seg, nb, kc, N);
             } else {
-                GainLineAccParams<T> kb{a1, a2, pseg, dirw, segs, tw, c.dir0, c.seg0};
+                GainLineAccParams<T> kb{a1, a2, pseg, dirw, segs, tw, c.dir0, c.seg0, a_bs, s_bs};
                 be->mark(BFSM_K_GAIN_LINE, (2.0 * c.n + c.n_seg) * Gc);
-                be->template launch<K::GainLineAcc, T>(N, c.n_seg, kb, N);
+                be->template launch<K::GainLineAcc, T>(N, c.n_seg, nb, kb, N);
             }
         }
         if (plan.exact_reductions && slab_count) {   // one forward tile pass per segment, all chunks at once
-            GainFwdParams<T> kc{pseg, slab, ones, segs_unit, tw, 0, 0};
+            GainFwdParams<T> kc{pseg, slab, ones, segs_unit, tw, 0, 0, s_bs, s_bs};
             be->mark(BFSM_K_GAIN_FWD, 1.0 * (double)slab_count * Gc);
-            be->template launch<K::GainFwd, T>(N, (int)slab_count, kc, N);
+            be->template launch<K::GainFwd, T>(N, (int)slab_count, nb, kc, N);
         }
-        ReduceParams<T> kr{slab, qhat, beta1, segs, (int)slab_count, plan.n2stride};
+        ReduceParams<T> kr{slab, qhat, beta1, segs, (int)slab_count, plan.n2stride, s_bs};
         be->mark(BFSM_K_REDUCE, ((double)slab_count + 1.0) * Gc);
-        be->template launch<K::Reduce, T>((int)((plan.G() + 255) / 256), 1, kr, N);
+        be->template launch<K::Reduce, T>((int)((plan.G() + 255) / 256), nb, 1, kr, N);
     }
 
     // Loss term + final inverse transforms + combine  (CUDABoltzmannOperator.cu:193-216)
     // with_loss = false: Q = Re IFFT(qhat) only -- the partial result a rank contributes when the caller sums Q
     // itself (half the bytes of summing Q_hat) and another rank adds the loss term.
-    void finish(double* Q_dev, const double* f_dev, bool with_loss = true) {
+    void finish(double* Q_dev, const double* f_dev, bool with_loss = true, int nb = 1) {
         const int N = plan.N;
-        const double Gc = (double)plan.G() * cbytes();
+        const double Gc = (double)plan.G() * cbytes() * nb;
         TailInvParams<T> ta{qhat, fhat, beta2, tg, tl, tw};
         be->mark(BFSM_K_TAIL, (with_loss ? 4.0 : 2.0) * Gc);
-        be->template launch<K::TailInv, T>(N, with_loss ? 2 : 1, ta, N);
+        be->template launch<K::TailInv, T>(N, with_loss ? 2 : 1, nb, ta, N);
         TailLineParams<T> tb{tg, tl, f_dev, Q_dev, tw, with_loss ? 1 : 0};
         be->mark(BFSM_K_TAIL, (with_loss ? 3.0 : 1.5) * Gc);
-        be->template launch<K::TailLine, T>(N, 1, tb, N);
+        be->template launch<K::TailLine, T>(N, nb, 1, tb, N);
     }
 
     // In-place batched 3-D transform on user data (bfsm_fft3d)
@@ -349,14 +360,14 @@ struct Pipeline {
         LineParams<T> p{data, data, tw};
         if (sign < 0) {
             be->mark(-1, 0);
-            be->template launch<K::TileFwd, T>(N, batch, p, N);
+            be->template launch<K::TileFwd, T>(N, batch, 1, p, N);
             be->mark(-1, 0);
-            be->template launch<K::LineFwd, T>(N, batch, p, N);
+            be->template launch<K::LineFwd, T>(N, batch, 1, p, N);
         } else {
             be->mark(-1, 0);
-            be->template launch<K::LineInv, T>(N, batch, p, N);
+            be->template launch<K::LineInv, T>(N, batch, 1, p, N);
             be->mark(-1, 0);
-            be->template launch<K::TileInv, T>(N, batch, p, N);
+            be->template launch<K::TileInv, T>(N, batch, 1, p, N);
         }
         return BFSM_OK;
     }

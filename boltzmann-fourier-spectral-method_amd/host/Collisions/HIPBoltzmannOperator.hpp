@@ -34,12 +34,17 @@ public:
     void setDevice(int ordinal) { device_ = ordinal; }
     void setDirectionShard(long long begin, long long end) { dir_begin_ = begin; dir_end_ = end; }
     void setMaxChunk(int n) { max_chunk_ = n; }
-    void setProfiling(bool on) { flags_ = on ? BFSM_FLAG_PROFILE : BFSM_FLAG_NONE; }
+    void setProfiling(bool on) { flags_ = on ? (flags_ | BFSM_FLAG_PROFILE) : (flags_ & ~BFSM_FLAG_PROFILE); }
+    void setExactReductions(bool on) { flags_ = on ? (flags_ | BFSM_FLAG_EXACT_REDUCTIONS) : (flags_ & ~BFSM_FLAG_EXACT_REDUCTIONS); }
+    void setMaxBatch(int n) { max_batch_ = n; }
 
     void initialize() override;
     std::string getBackendName() const override { return bfsm_backend_name(); }
     void computeCollision(double* Q, const double* f_in) override;      // device pointers, blocking
     void operator()(double* Q, const double* f_in) override { computeCollision(Q, f_in); }
+
+    // Batch of n_batch <= setMaxBatch() distributions, [n_batch][Nvx*Nvy*Nvz] device arrays, one set of launches.
+    void computeCollisionBatch(double* Q, const double* f_in, int n_batch);
 
     // Sharded evaluation (multi-GPU): partial gain -> caller's RCCL reduce on qhatBuffer() -> finish.
     void gainPartial(const double* f_in, void* stream = nullptr);
@@ -64,4 +69,5 @@ private:
     long long dir_begin_ = 0, dir_end_ = 0;
     int max_chunk_ = 0;
     int flags_ = BFSM_FLAG_NONE;
+    int max_batch_ = 0;
 };

@@ -34,13 +34,17 @@ void BoltzmannOperator<HIP_Backend>::initialize() {
     d.gamma = gamma; d.b_gamma = b_gamma; d.L = L;
     d.precision = precision_; d.device = device_;
     d.dir_begin = dir_begin_; d.dir_end = dir_end_;
-    d.max_chunk = max_chunk_; d.flags = flags_;
+    d.max_chunk = max_chunk_; d.flags = flags_; d.max_batch = max_batch_;
     if (handle_) { bfsm_destroy(handle_); handle_ = nullptr; }
     check(bfsm_create(&d, &handle_), "initialize");
 }
 
 void BoltzmannOperator<HIP_Backend>::computeCollision(double* Q, const double* f_in) {
     check(bfsm_collide(handle_, Q, f_in), "computeCollision");
+}
+
+void BoltzmannOperator<HIP_Backend>::computeCollisionBatch(double* Q, const double* f_in, int n_batch) {
+    check(bfsm_collide_batch(handle_, Q, f_in, n_batch), "computeCollisionBatch");
 }
 
 void BoltzmannOperator<HIP_Backend>::gainPartial(const double* f_in, void* stream) {

@@ -81,6 +81,7 @@ typedef struct bfsm_desc {
     int max_chunk;            /* directions resident at once (0 = default 1024: the whole shard in one pass when it
                                  fits; scratch = 2 * chunk * G complex); bounds scratch, not results                 */
     int flags;                /* BFSM_FLAG_*                              */
+    int max_batch;            /* distributions per bfsm_collide_batch call (0/1 = single); scratch scales with it */
 } bfsm_desc;
 
 /* Per-kernel accounting filled when BFSM_FLAG_PROFILE is set (all zero otherwise). */
@@ -112,6 +113,13 @@ int bfsm_collide(bfsm_handle h, double* Q_dev, const double* f_dev);
 /* Same, enqueued on `stream` (a hipStream_t cast to void*; NULL = the handle's own stream) without the final
  * host synchronisation. */
 int bfsm_collide_async(bfsm_handle h, double* Q_dev, const double* f_dev, void* stream);
+
+/* Batch of distributions (new functionality): f_dev and Q_dev hold n_batch <= desc.max_batch
+ * consecutive N^3 arrays; every kernel launch covers the whole batch (one more grid dimension), so the quadrature
+ * tables are shared and small grids (N = 16, 32) fill the GPU.  Member i of the result is bitwise identical to
+ * bfsm_collide on member i alone.  Batches are independent: on several GPUs they shard without any collective. */
+int bfsm_collide_batch(bfsm_handle h, double* Q_dev, const double* f_dev, int n_batch);
+int bfsm_collide_batch_async(bfsm_handle h, double* Q_dev, const double* f_dev, int n_batch, void* stream);
 
 /*
  * Sharded evaluation (new functionality: the reference is single-device).  Every rank calls

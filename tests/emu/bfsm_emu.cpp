@@ -20,13 +20,14 @@ namespace emu {
 
 struct Sched;
 struct EmuCtx {
-    int tid_, nthreads_, bx_, by_;
+    int tid_, nthreads_, bx_, by_, bz_;
     unsigned char* smem;
     Sched* sched;
     int tid() const { return tid_; }
     int nthreads() const { return nthreads_; }
     int bx() const { return bx_; }
     int by() const { return by_; }
+    int bz() const { return bz_; }
     int uniform(int v, int) const { return v; }
     template <class U> U* lds() const { return reinterpret_cast<U*>(smem); }
     template <class U> U ldc(const U* p) const { return *p; }
@@ -63,14 +64,14 @@ struct Sched {
     }
     void yield(State st) { const int me = current; state[me] = st; swapcontext(&ctxs[me], &main_ctx); }
 
-    void run_block(int nthreads, int bx, int by, unsigned char* smem, void (*fn)(void*, EmuCtx&), void* a) {
+    void run_block(int nthreads, int bx, int by, int bz, unsigned char* smem, void (*fn)(void*, EmuCtx&), void* a) {
         entry = fn; arg = a;
         if ((int)ctxs.size() < nthreads) { ctxs.resize(nthreads); stacks.resize((size_t)nthreads * STACK); }
         state.assign(nthreads, RUN);
         ectx.resize(nthreads);
         active() = this;
         for (int t = 0; t < nthreads; ++t) {
-            ectx[t] = EmuCtx{t, nthreads, bx, by, smem, this};
+            ectx[t] = EmuCtx{t, nthreads, bx, by, bz, smem, this};
             getcontext(&ctxs[t]);
             ctxs[t].uc_stack.ss_sp = stacks.data() + (size_t)t * STACK;
             ctxs[t].uc_stack.ss_size = STACK;
@@ -148,26 +149,26 @@ struct EmuBackend {
     }
 
     template <bfsm::K kind, int N, typename T, class P>
-    void launch_n(int gx, int gy, const P& prm) {
+    void launch_n(int gx, int gy, int gz, const P& prm) {
         const int threads = kind == bfsm::K::Reduce ? 256 : bfsm::Wg<N>::THREADS;
         smem.assign((size_t)bfsm::Wg<N>::LDS_ELEMS * sizeof(bfsm::cx<T>), 0xCD);
         P copy = prm;
-        for (int by = 0; by < gy; ++by)
-            for (int bx = 0; bx < gx; ++bx)
-            {
-                sched.run_block(threads, bx, by, smem.data(), &body<kind, N, T, P>, &copy);
-                if (sched.deadlock) failed = true;
-            }
+        for (int bz = 0; bz < gz; ++bz)
+            for (int by = 0; by < gy; ++by)
+                for (int bx = 0; bx < gx; ++bx) {
+                    sched.run_block(threads, bx, by, bz, smem.data(), &body<kind, N, T, P>, &copy);
+                    if (sched.deadlock) failed = true;
+                }
     }
 
     template <bfsm::K kind, typename T, class P>
-    void launch(int gx, int gy, const P& prm, int N) {
+    void launch(int gx, int gy, int gz, const P& prm, int N) {
         switch (N) {
-            case 16: launch_n<kind, 16, T>(gx, gy, prm); break;
-            case 32: launch_n<kind, 32, T>(gx, gy, prm); break;
-            case 64: launch_n<kind, 64, T>(gx, gy, prm); break;
+            case 16: launch_n<kind, 16, T>(gx, gy, gz, prm); break;
+            case 32: launch_n<kind, 32, T>(gx, gy, gz, prm); break;
+            case 64: launch_n<kind, 64, T>(gx, gy, gz, prm); break;
             case 128:
-                if constexpr (sizeof(T) == 4) launch_n<kind, 128, T>(gx, gy, prm);
+                if constexpr (sizeof(T) == 4) launch_n<kind, 128, T>(gx, gy, gz, prm);
                 break;
             default: break;
         }
@@ -175,18 +176,19 @@ struct EmuBackend {
 };
 
 template <typename T>
-int collide_t(const bfsm_desc* d, const double* f, double* Q, double* qhat_out) {
+int collide_t(const bfsm_desc* d, const double* f, double* Q, double* qhat_out, int nb) {
     EmuBackend be;
     bfsm::Pipeline<T, EmuBackend> p;
     std::string err;
     int rc = p.init(*d, &be, err);
     if (rc) return rc;
-    p.gain_partial(f);
+    if (nb < 1 || nb > p.max_batch) return BFSM_ERR_INVALID;
+    p.gain_partial(f, nb);
     if (qhat_out) {
-        const size_t G = p.plan.G();
+        const size_t G = p.plan.G() * (size_t)nb;
         for (size_t i = 0; i < G; ++i) { qhat_out[2 * i] = (double)p.qhat[i].x; qhat_out[2 * i + 1] = (double)p.qhat[i].y; }
     }
-    if (Q) p.finish(Q, f);
+    if (Q) p.finish(Q, f, true, nb);
     p.destroy();
     return be.failed ? 99 : 0;
 }
@@ -238,11 +240,16 @@ extern "C" {
 
 // Emulated bfsm_gain_partial + bfsm_finish on host arrays.  qhat_out (optional): 2*G doubles, spectral layout
 // [lx][lz][ly].  Q may be NULL to skip the tail.
-int bfsm_emu_collide(const bfsm_desc* d, const double* f, double* Q, double* qhat_out) {
+int bfsm_emu_collide_batch(const bfsm_desc* d, const double* f, double* Q, double* qhat_out, int n_batch) {
     std::string err;
     int rc = bfsm::validate_desc(*d, err);
     if (rc) return rc;
-    return d->precision == BFSM_F64 ? emu::collide_t<double>(d, f, Q, qhat_out) : emu::collide_t<float>(d, f, Q, qhat_out);
+    return d->precision == BFSM_F64 ? emu::collide_t<double>(d, f, Q, qhat_out, n_batch)
+                                    : emu::collide_t<float>(d, f, Q, qhat_out, n_batch);
+}
+
+int bfsm_emu_collide(const bfsm_desc* d, const double* f, double* Q, double* qhat_out) {
+    return bfsm_emu_collide_batch(d, f, Q, qhat_out, 1);
 }
 
 // Emulated bfsm_finish on a caller-provided (already reduced) Q_gain_hat in the spectral layout.

@@ -27,13 +27,13 @@ def lib():
     return _LIB
 
 
-def make_desc(nv, gl, sph, gamma, b_gamma, L, precision=64, dir_range=(0, 0), max_chunk=0, flags=0):
+def make_desc(nv, gl, sph, gamma, b_gamma, L, precision=64, dir_range=(0, 0), max_chunk=0, flags=0, max_batch=0):
     """gl = (nodes, weights), sph = (x, y, z, w).  Returns (Desc, keepalive)."""
     from bfsm import capi
     dp = ctypes.POINTER(ctypes.c_double)
     keep = [np.ascontiguousarray(a, dtype=np.float64) for a in (gl[0], gl[1], sph[3], sph[0], sph[1], sph[2])]
     d = capi.Desc(nv, nv, nv, len(keep[0]), len(keep[2]), *[a.ctypes.data_as(dp) for a in keep],
-                  gamma, b_gamma, L, precision, 0, dir_range[0], dir_range[1], max_chunk, flags)
+                  gamma, b_gamma, L, precision, 0, dir_range[0], dir_range[1], max_chunk, flags, max_batch)
     return d, keep
 
 
@@ -127,3 +127,22 @@ class EmuOperator:
         if rc:
             raise RuntimeError(f"bfsm_emu_finish rc={rc}")
         Q.copy_(torch.from_numpy(out))
+
+
+def collide_batch(fs, gl, sph, gamma, b_gamma, L, precision=64, max_chunk=0, flags=0):
+    """fs: [n_batch][nv][nv][nv]; one emulated bfsm_collide_batch call.  Returns Q with the same shape."""
+    fs = np.ascontiguousarray(fs, dtype=np.float64)
+    nb, nv = fs.shape[0], fs.shape[1]
+    d, keep = make_desc(nv, gl, sph, gamma, b_gamma, L, precision, (0, 0), max_chunk, flags, max_batch=nb)
+    L_ = lib()
+    dp = ctypes.POINTER(ctypes.c_double)
+    if not hasattr(L_.bfsm_emu_collide_batch, "_typed"):
+        from bfsm import capi
+        L_.bfsm_emu_collide_batch.argtypes = [ctypes.POINTER(capi.Desc), dp, dp, dp, ctypes.c_int]
+        L_.bfsm_emu_collide_batch.restype = ctypes.c_int
+        L_.bfsm_emu_collide_batch._typed = True
+    Q = np.empty_like(fs)
+    rc = L_.bfsm_emu_collide_batch(ctypes.byref(d), fs.ctypes.data_as(dp), Q.ctypes.data_as(dp), None, nb)
+    if rc:
+        raise RuntimeError(f"bfsm_emu_collide_batch rc={rc}")
+    return Q

@@ -174,3 +174,19 @@ def test_general_collision_kernels(oracle, gamma, b_gamma):
     for flags in (0, EXACT):
         Q, _ = E.collide(f, gl, sph, gamma, b_gamma, L, 64, flags=flags)
         assert np.abs(Q - Qo).max() <= 1e-12 * np.abs(Qo).max()
+
+
+@pytest.mark.parametrize("flags", [0, EXACT])
+def test_batch_of_distributions(oracle, flags):
+    """n_batch distributions through one set of launches == the same distributions one at a time
+    (bitwise), and == the oracle."""
+    f0, _, L, _ = oracle.bkw(16)
+    fs = np.stack([oracle.perturbed_input(f0, seed=s, amp=0.1 + 0.05 * i) for i, s in enumerate((1, 2, 3))])
+    gl = oracle.gauss_legendre(3, 0.0, R)
+    sph = oracle.spherical_design(12)
+    Qb = E.collide_batch(fs, gl, sph, GAMMA, B_GAMMA, L, max_chunk=7, flags=flags)
+    for i in range(3):
+        Qi, _ = E.collide(fs[i], gl, sph, GAMMA, B_GAMMA, L, 64, max_chunk=7, flags=flags)
+        assert np.array_equal(Qb[i], Qi)
+        Qo = oracle.collide(fs[i], gl, sph, GAMMA, B_GAMMA, L)
+        assert np.abs(Qb[i] - Qo).max() <= 1e-12 * np.abs(Qo).max()

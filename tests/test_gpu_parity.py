@@ -24,7 +24,7 @@ def torch_cuda():
 
 
 def _make(bfsm, nv, n_gl, n_sph, precision=64, shard=None, max_chunk=0, profile=False, exact=False, gamma=None,
-          b_gamma=None):
+          b_gamma=None, max_batch=0):
     c = dict(bfsm.reference_constants())
     if gamma is not None:
         c["gamma"], c["b_gamma"] = gamma, b_gamma
@@ -38,6 +38,7 @@ def _make(bfsm, nv, n_gl, n_sph, precision=64, shard=None, max_chunk=0, profile=
         op.setMaxChunk(max_chunk)
     op.setProfiling(profile)
     op.setExactReductions(exact)
+    op.setMaxBatch(max_batch)
     op.initialize()
     return op
 
@@ -341,3 +342,33 @@ def test_bkw_relaxation_time_stepping(torch_cuda):
     assert a["mass_drift"] < 5e-4 and a["energy_drift"] < 5e-3
     assert a["entropy_end"] < a["entropy_start"]
     assert abs(a["entropy_end"] - a["entropy_exact_end"]) < 1e-3 * abs(a["entropy_exact_end"])
+
+
+@pytest.mark.parametrize("nv,n_gl,n_sph,nb", [(16, 8, 32, 9), (32, 4, 12, 4), (64, 2, 12, 2)])
+@pytest.mark.parametrize("exact", [False, True])
+def test_batch_of_distributions(torch_cuda, oracle, nv, n_gl, n_sph, nb, exact):
+    """bfsm_collide_batch == bfsm_collide member by member (bitwise) == oracle; a shorter batch than
+    max_batch and an oversized one (rejected) are covered too."""
+    import bfsm
+    torch = torch_cuda
+    f0 = bfsm.bkw_solution(nv)[0]
+    fs_h = np.stack([bfsm.perturbed_input(f0, seed=100 + i, amp=0.05 * (i + 1)) for i in range(nb)])
+    op = _make(bfsm, nv, n_gl, n_sph, exact=exact, max_batch=nb)
+    fs = torch.from_numpy(fs_h).cuda()
+    Qb = torch.empty_like(fs)
+    op.computeCollisionBatch(Qb, fs, nb)
+    Qb_h = Qb.cpu().numpy()
+    single = torch.empty(nv ** 3, dtype=torch.float64, device="cuda")
+    for i in (0, nb - 1):
+        op(single, fs[i].reshape(-1).contiguous())
+        assert np.array_equal(single.cpu().numpy().reshape(nv, nv, nv), Qb_h[i])
+        ref = _oracle(oracle, fs_h[i], n_gl, n_sph)
+        assert np.abs(Qb_h[i] - ref).max() <= TOL64 * np.abs(ref).max()
+    Q2 = torch.empty(2 * nv ** 3, dtype=torch.float64, device="cuda") if nb > 2 else None
+    if Q2 is not None:
+        op.computeCollisionBatch(Q2, fs[:2].contiguous(), 2)
+        assert np.array_equal(Q2.cpu().numpy().reshape(2, nv, nv, nv), Qb_h[:2])
+    big = torch.zeros((nb + 1) * nv ** 3, dtype=torch.float64, device="cuda")
+    with pytest.raises(bfsm.BfsmError):
+        op.computeCollisionBatch(torch.empty_like(big), big, nb + 1)
+    op.destroy()
