@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--max-chunk", type=int, default=0)
+    ap.add_argument("--precision", type=int, default=0, choices=(0, 32, 64),
+                    help="override the workload's arithmetic type (0 = the workload's own)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-exact", action="store_true", help="skip the extra opt-in exact-reduction measurement")
@@ -93,15 +95,22 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the collision operator has no CPU path", file=sys.stderr)
         sys.exit(3)
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU.  (Rehearsals on a single-GPU box may set BFSM_BENCH_BACKEND=gloo: the ranks then share
+    # device 0 and the collective goes through the host -- same code path, meaningless timings.)
+    backend = os.environ.get("BFSM_BENCH_BACKEND", "nccl")
+    dev = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     w = WORKLOADS[args.workload]
-    nv, n_gl, n_sph, prec = w["nv"], w["n_gl"], w["n_sph"], w["precision"]
+    nv, n_gl, n_sph, prec = w["nv"], w["n_gl"], w["n_sph"], (args.precision or w["precision"])
     B = n_gl * n_sph
     c = bfsm.reference_constants()
     f_h = bfsm.bkw_solution(nv)[0]
@@ -110,7 +119,7 @@ def main():
         op = bfsm.HIPBoltzmannOperator(bfsm.GaussLegendreQuadrature(n_gl, 0.0, c["R"]), bfsm.SphericalDesign(n_sph),
                                        nv, nv, nv, c["gamma"], c["b_gamma"], c["L"])
         op.setPrecision(prec)
-        op.setDevice(local_rank)
+        op.setDevice(dev)
         if world > 1:
             op.setDirectionShard(*bfsm.shard_range(B, rank, world))
         if args.max_chunk:
