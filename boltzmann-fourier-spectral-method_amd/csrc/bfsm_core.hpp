@@ -124,7 +124,13 @@ struct Wg {
     static constexpr int THREADS = N * T;     // one N x N tile per workgroup
     static constexpr int LS = N + 1;          // LDS row stride (elements); odd => transposed reads conflict-free
     static constexpr int LDS_ELEMS = N * LS;
-    static_assert(E * T == N && Q * T == E, "geometry");
+    // Line kernels (1-D passes along x) only need a set of independent columns, not a whole tile: they take NPL
+    // columns per workgroup.  At N = 128 that is half a row, which halves the exchange buffer (66 KiB in fp32) and
+    // lets two workgroups share a CU; the 2-D tile kernels keep N columns.
+    static constexpr int NPL = N > 64 ? 64 : N;
+    static constexpr int LINE_THREADS = NPL * T;
+    static constexpr int LINE_LDS_ELEMS = N * (NPL + 1);
+    static_assert(E * T == N && Q * T == E && N % NPL == 0, "geometry");
 };
 
 // ---- one distributed 1-D transform -------------------------------------------------------------------------
@@ -138,9 +144,9 @@ BFSM_HD void load_twiddles(cx<T>* twr, const cx<T>* tw, int u, Ctx& ctx) {
     for (int k1 = 1; k1 < Wg<N>::E; ++k1) twr[k1 - 1] = ctx.ldc(tw + u * k1);
 }
 
-template <int N, int SGN, typename T, class Ctx>
-BFSM_HD void fft_line(cx<T>* v, cx<T>* lds, int p, int u, const cx<T>* twr, Ctx& ctx) {
-    constexpr int E = Wg<N>::E, TT = Wg<N>::T, Q = Wg<N>::Q, LS = Wg<N>::LS;
+template <int N, int NP, int SGN, typename T, class Ctx>
+BFSM_HD void fft_line_np(cx<T>* v, cx<T>* lds, int p, int u, const cx<T>* twr, Ctx& ctx) {
+    constexpr int E = Wg<N>::E, TT = Wg<N>::T, Q = Wg<N>::Q, LS = NP + 1;   // p in [0, NP): LDS column
     SmallDft<E, SGN, T>::run(v);
 #pragma unroll
     for (int k1 = 1; k1 < E; ++k1) {
@@ -163,6 +169,11 @@ BFSM_HD void fft_line(cx<T>* v, cx<T>* lds, int p, int u, const cx<T>* twr, Ctx&
     for (int q = 0; q < Q; ++q)
 #pragma unroll
         for (int k2 = 0; k2 < TT; ++k2) v[q + Q * k2] = w2[q * TT + k2];
+}
+
+template <int N, int SGN, typename T, class Ctx>
+BFSM_HD void fft_line(cx<T>* v, cx<T>* lds, int p, int u, const cx<T>* twr, Ctx& ctx) {
+    fft_line_np<N, N, SGN, T>(v, lds, p, u, twr, ctx);
 }
 
 // ---- 2-D transform of an N x N tile with transposition -------------------------------------------------------
@@ -334,19 +345,20 @@ BFSM_HD void body_tile_c2c(const LineParams<T>& prm, Ctx& ctx) {
     for (int m = 0; m < E; ++m) prm.out[base + (u + TT * m) * N + p] = v[m];
 }
 
-// Generic x-axis pass.  grid.x = N (rows of N contiguous elements inside a plane), grid.y = batch.
+// Generic x-axis pass.  grid.x = N*N/NPL (blocks of NPL contiguous columns of the inner N*N space), grid.y = batch.
 template <int N, int SGN, typename T, class Ctx>
 BFSM_HD void body_line(const LineParams<T>& prm, Ctx& ctx) {
     constexpr int E = Wg<N>::E, TT = Wg<N>::T;
-    const int tid = ctx.tid(), p = tid % N, u = ctx.uniform(tid / N, N);
-    const size_t base = (size_t)ctx.by() * N * N * N + (size_t)ctx.bx() * N + p;
+    constexpr int NPL = Wg<N>::NPL;
+    const int tid = ctx.tid(), p = tid % NPL, u = ctx.uniform(tid / NPL, NPL);   // p: column inside this block of NPL
+    const size_t base = (size_t)ctx.by() * N * N * N + (size_t)ctx.bx() * NPL + p;
     cx<T>* lds = ctx.template lds<cx<T>>();
     cx<T> twr[E - 1];
     load_twiddles<N, T>(twr, prm.tw, u, ctx);
     cx<T> v[E];
 #pragma unroll
     for (int m = 0; m < E; ++m) v[m] = prm.in[base + (size_t)(u + TT * m) * N * N];
-    fft_line<N, SGN, T>(v, lds, p, u, twr, ctx);
+    fft_line_np<N, NPL, SGN, T>(v, lds, p, u, twr, ctx);
 #pragma unroll
     for (int m = 0; m < E; ++m) prm.out[base + (size_t)(u + TT * m) * N * N] = v[m];
 }
@@ -396,13 +408,14 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
     }
 }
 
-// KB.  grid = (N rows y, directions of the chunk).  x-part of the two inverse transforms, hadamard_product
+// KB.  grid = (N*N/NPL column blocks, directions of the chunk).  x-part of the two inverse transforms, hadamard_product
 // (BoltzmannCUDAKernels.cu:62-74) in registers, x-part of the forward transform (CUDABoltzmannOperator.cu:175-178).
 template <int N, typename T, class Ctx>
 BFSM_HD void body_gain_line(const GainLineParams<T>& prm, Ctx& ctx) {
     constexpr int E = Wg<N>::E, TT = Wg<N>::T;
-    const int tid = ctx.tid(), p = tid % N, u = ctx.uniform(tid / N, N);
-    const size_t base = (size_t)ctx.bz() * prm.a_bstride + (size_t)ctx.by() * N * N * N + (size_t)ctx.bx() * N + p;
+    constexpr int NPL = Wg<N>::NPL;
+    const int tid = ctx.tid(), p = tid % NPL, u = ctx.uniform(tid / NPL, NPL);   // p: column inside this block of NPL
+    const size_t base = (size_t)ctx.bz() * prm.a_bstride + (size_t)ctx.by() * N * N * N + (size_t)ctx.bx() * NPL + p;
     cx<T>* lds = ctx.template lds<cx<T>>();
     cx<T> twr[E - 1];
     load_twiddles<N, T>(twr, prm.tw, u, ctx);
@@ -411,11 +424,11 @@ BFSM_HD void body_gain_line(const GainLineParams<T>& prm, Ctx& ctx) {
     for (int m = 0; m < E; ++m) a[m] = ctx.ld_stream(prm.a1 + base + (size_t)(u + TT * m) * N * N);
 #pragma unroll
     for (int m = 0; m < E; ++m) b[m] = ctx.ld_stream(prm.a2 + base + (size_t)(u + TT * m) * N * N);
-    fft_line<N, +1, T>(a, lds, p, u, twr, ctx);
-    fft_line<N, +1, T>(b, lds, p, u, twr, ctx);
+    fft_line_np<N, NPL, +1, T>(a, lds, p, u, twr, ctx);
+    fft_line_np<N, NPL, +1, T>(b, lds, p, u, twr, ctx);
 #pragma unroll
     for (int m = 0; m < E; ++m) a[m] = cmul(a[m], b[m]);
-    fft_line<N, -1, T>(a, lds, p, u, twr, ctx);
+    fft_line_np<N, NPL, -1, T>(a, lds, p, u, twr, ctx);
 #pragma unroll
     for (int m = 0; m < E; ++m) ctx.st_stream(prm.a1 + base + (size_t)(u + TT * m) * N * N, a[m]);
 }
@@ -427,12 +440,13 @@ BFSM_HD void body_gain_line(const GainLineParams<T>& prm, Ctx& ctx) {
 template <int N, typename T, class Ctx>
 BFSM_HD void body_gain_line_acc(const GainLineAccParams<T>& prm, Ctx& ctx) {
     constexpr int E = Wg<N>::E, TT = Wg<N>::T;
-    const int tid = ctx.tid(), p = tid % N, u = ctx.uniform(tid / N, N);
+    constexpr int NPL = Wg<N>::NPL;
+    const int tid = ctx.tid(), p = tid % NPL, u = ctx.uniform(tid / NPL, NPL);   // p: column inside this block of NPL
     cx<T>* lds = ctx.template lds<cx<T>>();
     cx<T> twr[E - 1];
     load_twiddles<N, T>(twr, prm.tw, u, ctx);
     const Segment seg = prm.segs[prm.seg0 + ctx.by()];
-    const size_t row = (size_t)ctx.bx() * N + p;
+    const size_t row = (size_t)ctx.bx() * NPL + p;
     cx<T> acc[E];
 #pragma unroll
     for (int m = 0; m < E; ++m) acc[m] = {(T)0, (T)0};
@@ -443,8 +457,8 @@ BFSM_HD void body_gain_line_acc(const GainLineAccParams<T>& prm, Ctx& ctx) {
         for (int m = 0; m < E; ++m) a[m] = ctx.ld_stream(prm.a1 + base + (size_t)(u + TT * m) * N * N);
 #pragma unroll
         for (int m = 0; m < E; ++m) b[m] = ctx.ld_stream(prm.a2 + base + (size_t)(u + TT * m) * N * N);
-        fft_line<N, +1, T>(a, lds, p, u, twr, ctx);
-        fft_line<N, +1, T>(b, lds, p, u, twr, ctx);
+        fft_line_np<N, NPL, +1, T>(a, lds, p, u, twr, ctx);
+        fft_line_np<N, NPL, +1, T>(b, lds, p, u, twr, ctx);
         const T w = prm.dirw[prm.dir0 + d];
 #pragma unroll
         for (int m = 0; m < E; ++m) {
@@ -453,7 +467,7 @@ BFSM_HD void body_gain_line_acc(const GainLineAccParams<T>& prm, Ctx& ctx) {
             acc[m].y += w * pr.y;
         }
     }
-    fft_line<N, -1, T>(acc, lds, p, u, twr, ctx);
+    fft_line_np<N, NPL, -1, T>(acc, lds, p, u, twr, ctx);
     const size_t obase = (size_t)ctx.bz() * prm.pseg_bstride + (size_t)(prm.seg0 + ctx.by()) * N * N * N + row;
 #pragma unroll
     for (int m = 0; m < E; ++m) prm.pseg[obase + (size_t)(u + TT * m) * N * N] = acc[m];
@@ -550,19 +564,20 @@ BFSM_HD void body_tail_inv(const TailInvParams<T>& prm, Ctx& ctx) {
 template <int N, typename T, class Ctx>
 BFSM_HD void body_tail_line(const TailLineParams<T>& prm, Ctx& ctx) {
     constexpr int E = Wg<N>::E, TT = Wg<N>::T;
-    const int tid = ctx.tid(), p = tid % N, u = ctx.uniform(tid / N, N);
-    const size_t base = (size_t)ctx.by() * N * N * N + (size_t)ctx.bx() * N + p;
+    constexpr int NPL = Wg<N>::NPL;
+    const int tid = ctx.tid(), p = tid % NPL, u = ctx.uniform(tid / NPL, NPL);   // p: column inside this block of NPL
+    const size_t base = (size_t)ctx.by() * N * N * N + (size_t)ctx.bx() * NPL + p;
     cx<T>* lds = ctx.template lds<cx<T>>();
     cx<T> twr[E - 1];
     load_twiddles<N, T>(twr, prm.tw, u, ctx);
     cx<T> g[E], l[E];
 #pragma unroll
     for (int m = 0; m < E; ++m) g[m] = prm.tg[base + (size_t)(u + TT * m) * N * N];
-    fft_line<N, +1, T>(g, lds, p, u, twr, ctx);
+    fft_line_np<N, NPL, +1, T>(g, lds, p, u, twr, ctx);
     if (prm.with_loss) {
 #pragma unroll
         for (int m = 0; m < E; ++m) l[m] = prm.tl[base + (size_t)(u + TT * m) * N * N];
-        fft_line<N, +1, T>(l, lds, p, u, twr, ctx);
+        fft_line_np<N, NPL, +1, T>(l, lds, p, u, twr, ctx);
 #pragma unroll
         for (int m = 0; m < E; ++m) {
             const size_t i = base + (size_t)(u + TT * m) * N * N;

@@ -57,12 +57,20 @@ struct DevCtx {
 };
 
 template <K kind, int N>
-constexpr int kernel_threads() { return kind == K::Reduce ? 256 : Wg<N>::THREADS; }
+constexpr int kernel_threads() {
+    return kind == K::Reduce ? 256 : (is_line_kind(kind) ? Wg<N>::LINE_THREADS : Wg<N>::THREADS);
+}
+template <K kind, int N, typename T>
+constexpr size_t kernel_lds_bytes() {
+    return kind == K::Reduce ? 0 : (size_t)(is_line_kind(kind) ? Wg<N>::LINE_LDS_ELEMS : Wg<N>::LDS_ELEMS) * sizeof(cx<T>);
+}
 
 // Minimum waves per SIMD the register allocator must leave room for.  N=64: a 512-thread workgroup is 2 waves per
 // SIMD and its 65 KiB tile lets two workgroups share a CU's 160 KiB LDS, so ask for 4 (<= 128 VGPRs).
 template <K kind, int N>
-constexpr int kernel_min_waves() { return (kind != K::Reduce && N == 64) ? 4 : 1; }
+constexpr int kernel_min_waves() {
+    return (kind != K::Reduce && (N == 64 || (N == 128 && is_line_kind(kind)))) ? 4 : 1;
+}
 
 template <K kind, int N, typename T, class P>
 __global__ void __launch_bounds__((kernel_threads<kind, N>()), (kernel_min_waves<kind, N>())) bfsm_kernel(const P prm) {
@@ -125,7 +133,7 @@ struct HipBackend {
     template <K kind, int N, typename T, class P>
     void launch_n(int gx, int gy, int gz, const P& prm) {
         constexpr int threads = kernel_threads<kind, N>();
-        constexpr size_t lds = kind == K::Reduce ? 0 : (size_t)Wg<N>::LDS_ELEMS * sizeof(cx<T>);
+        constexpr size_t lds = kernel_lds_bytes<kind, N, T>();
         auto fn = bfsm_kernel<kind, N, T, P>;
         static std::once_flag once;   // one per instantiation
         std::call_once(once, [&] {

@@ -211,6 +211,11 @@ HostTables<T> build_tables(const bfsm_desc& d, const PlanInfo& p) {
 // Kernel identifiers the backend dispatches on.
 enum class K { TileFwdReal, LineFwd, LineInv, TileFwd, TileInv, GainInv, GainLine, GainFwd, Reduce, TailInv, TailLine, GainLineAcc };
 
+// 1-D (x-axis) kernels take Wg<N>::NPL columns per workgroup, 2-D tile kernels a whole N x N tile.
+constexpr bool is_line_kind(K k) {
+    return k == K::LineFwd || k == K::LineInv || k == K::GainLine || k == K::GainLineAcc || k == K::TailLine;
+}
+
 // Device-resident state of one handle.  `Backend` supplies:
 //   void* alloc(size_t), void release(void*), void upload(void* dst, const void* src, size_t), void zero(void*, size_t)
 //   template <K kind, typename T, class P> void launch(int grid_x, int grid_y, int grid_z, const P& params, int N)
@@ -295,6 +300,7 @@ struct Pipeline {
     }
 
     double cbytes() const { return (double)sizeof(cx<T>); }
+    int line_blocks() const { const int npl = plan.N > 64 ? 64 : plan.N; return plan.N * (plan.N / npl); }   // Wg<N>::NPL
 
     // f_hat = FFT(f), then the gain term of this shard into qhat (partial Q_gain_hat, spectral layout).
     // nb distributions f_dev[nb][G] are processed by the same launches (grid.z / grid.y = batch member); all
@@ -310,7 +316,7 @@ struct Pipeline {
             be->template launch<K::TileFwdReal, T>(N, nb, 1, pa, N);
             LineParams<T> pb{tg, fhat, tw};
             be->mark(BFSM_K_FFT_F, 2.0 * Gc);
-            be->template launch<K::LineFwd, T>(N, nb, 1, pb, N);
+            be->template launch<K::LineFwd, T>(line_blocks(), nb, 1, pb, N);
         }
         for (const Chunk& c : plan.chunks) {
             GainInvParams<T> ka{fhat, a1, a2, phx, phy, phz, tw, c.dir0, c.n, c.per_group, a_bs};
@@ -320,14 +326,14 @@ struct Pipeline {
             if (!plan.exact_reductions) {
                 GainLineParams<T> kb{a1, a2, tw, a_bs};
                 be->mark(BFSM_K_GAIN_LINE, 3.0 * c.n * Gc);
-                be->template launch<K::GainLine, T>(N, c.n, nb, kb, N);
+                be->template launch<K::GainLine, T>(line_blocks(), c.n, nb, kb, N);
                 GainFwdParams<T> kc{a1, slab, dirw, segs, tw, c.dir0, c.seg0, a_bs, s_bs};
                 be->mark(BFSM_K_GAIN_FWD, 1.0 * c.n * Gc);
                 be->template launch<K::GainFwd, T>(N, c.n_seg, nb, kc, N);
             } else {
                 GainLineAccParams<T> kb{a1, a2, pseg, dirw, segs, tw, c.dir0, c.seg0, a_bs, s_bs};
                 be->mark(BFSM_K_GAIN_LINE, (2.0 * c.n + c.n_seg) * Gc);
-                be->template launch<K::GainLineAcc, T>(N, c.n_seg, nb, kb, N);
+                be->template launch<K::GainLineAcc, T>(line_blocks(), c.n_seg, nb, kb, N);
             }
         }
         if (plan.exact_reductions && slab_count) {   // one forward tile pass per segment, all chunks at once
@@ -351,7 +357,7 @@ struct Pipeline {
         be->template launch<K::TailInv, T>(N, with_loss ? 2 : 1, nb, ta, N);
         TailLineParams<T> tb{tg, tl, f_dev, Q_dev, tw, with_loss ? 1 : 0};
         be->mark(BFSM_K_TAIL, (with_loss ? 3.0 : 1.5) * Gc);
-        be->template launch<K::TailLine, T>(N, nb, 1, tb, N);
+        be->template launch<K::TailLine, T>(line_blocks(), nb, 1, tb, N);
     }
 
     // In-place batched 3-D transform on user data (bfsm_fft3d)
@@ -362,10 +368,10 @@ struct Pipeline {
             be->mark(-1, 0);
             be->template launch<K::TileFwd, T>(N, batch, 1, p, N);
             be->mark(-1, 0);
-            be->template launch<K::LineFwd, T>(N, batch, 1, p, N);
+            be->template launch<K::LineFwd, T>(line_blocks(), batch, 1, p, N);
         } else {
             be->mark(-1, 0);
-            be->template launch<K::LineInv, T>(N, batch, 1, p, N);
+            be->template launch<K::LineInv, T>(line_blocks(), batch, 1, p, N);
             be->mark(-1, 0);
             be->template launch<K::TileInv, T>(N, batch, 1, p, N);
         }

@@ -150,8 +150,10 @@ struct EmuBackend {
 
     template <bfsm::K kind, int N, typename T, class P>
     void launch_n(int gx, int gy, int gz, const P& prm) {
-        const int threads = kind == bfsm::K::Reduce ? 256 : bfsm::Wg<N>::THREADS;
-        smem.assign((size_t)bfsm::Wg<N>::LDS_ELEMS * sizeof(bfsm::cx<T>), 0xCD);
+        const int threads = kind == bfsm::K::Reduce ? 256
+                            : (bfsm::is_line_kind(kind) ? bfsm::Wg<N>::LINE_THREADS : bfsm::Wg<N>::THREADS);
+        smem.assign((size_t)(bfsm::is_line_kind(kind) ? bfsm::Wg<N>::LINE_LDS_ELEMS : bfsm::Wg<N>::LDS_ELEMS) *
+                        sizeof(bfsm::cx<T>), 0xCD);
         P copy = prm;
         for (int bz = 0; bz < gz; ++bz)
             for (int by = 0; by < gy; ++by)

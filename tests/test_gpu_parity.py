@@ -372,3 +372,17 @@ def test_batch_of_distributions(torch_cuda, oracle, nv, n_gl, n_sph, nb, exact):
     with pytest.raises(bfsm.BfsmError):
         op.computeCollisionBatch(torch.empty_like(big), big, nb + 1)
     op.destroy()
+
+
+def test_n128_fp32_matches_oracle(torch_cuda, oracle):
+    """Config-5 grid (N=128, single precision, 192-point design is too slow for the CPU oracle: 12-point design,
+    two radial nodes): faithful and exact-reduction paths against the fp64 oracle at fp32 tolerance."""
+    import bfsm
+    nv, n_gl, n_sph = 128, 2, 12
+    f_h = bfsm.perturbed_input(bfsm.bkw_solution(nv)[0])
+    ref = _oracle(oracle, f_h, n_gl, n_sph)
+    for exact in (False, True):
+        op = _make(bfsm, nv, n_gl, n_sph, 32, exact=exact)
+        got = _collide(torch_cuda, op, f_h)
+        op.destroy()
+        assert np.abs(got - ref).max() <= TOL32 * np.abs(ref).max()
