@@ -11,8 +11,9 @@ reference driver (maxwell_bkw_cuda.cu:144-151).
          bench.py --gpus N --steps K --warmup W
 
 N > 1: the B = M_gl*M_sph quadrature directions are sharded contiguously over the ranks (strong scaling: the
-workload is fixed), each rank computes its partial Q_gain_hat, ONE RCCL all-reduce (torch.distributed "nccl")
-sums it over xGMI, every rank finishes the O(G) tail redundantly.
+workload is fixed); each rank computes its partial Q_gain_hat, inverse-transforms it (the transform is linear; rank 0
+also subtracts the loss term) and ONE RCCL all-reduce (torch.distributed "nccl") sums the real Q over xGMI
+(G doubles: half the bytes of summing Q_hat, and no kernel runs after the collective).
 
 Workloads (BASELINE.json configs):  cfg2 N=32,M_gl=8,ss009.048 | cfg3 N=64,M_gl=16,ss009.048 (default, the
 roofline configuration) | cfg4 N=64,M_gl=16,ss017.156 | cfg5 N=128,M_gl=30,ss019.192 fp32.
@@ -200,9 +201,12 @@ def main():
         dom = max(range(len(acc)), key=lambda i: acc[i][0])
         ms, nbytes, launches = acc[dom]
         achieved = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
+        # same command, FETCH doubled per MI355X_MICROARCH.md; profiles/summarize.py).  Only valid for the launch
+        # geometry it was collected on: the default single-GPU cfg3 run.
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and world == 1 and args.workload == "cfg3" and prec == 64 and not args.max_chunk:
             try:
                 traffic = json.load(open(tpath)).get(bfsm.KERNEL_NAMES[dom], {}).get("hbm_bytes_per_launch")
             except Exception:

@@ -53,6 +53,8 @@ class BfsmError(RuntimeError):
 
 
 def lib_path():
+    if os.environ.get("BFSM_LIB"):            # experiments: an alternative build of the same library
+        return os.environ["BFSM_LIB"]
     return os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "libbfsm_hip.so")
 
 

@@ -9,6 +9,10 @@
 
 #include "bfsm_pipeline.hpp"
 
+#ifndef BFSM_F32_N64_WAVES
+#define BFSM_F32_N64_WAVES 4
+#endif
+
 namespace bfsm {
 
 // ---- device execution context ---------------------------------------------------------------------------------
@@ -67,13 +71,16 @@ constexpr size_t kernel_lds_bytes() {
 
 // Minimum waves per SIMD the register allocator must leave room for.  N=64: a 512-thread workgroup is 2 waves per
 // SIMD and its 65 KiB tile lets two workgroups share a CU's 160 KiB LDS, so ask for 4 (<= 128 VGPRs).
-template <K kind, int N>
+template <K kind, int N, typename T>
 constexpr int kernel_min_waves() {
-    return (kind != K::Reduce && (N == 64 || (N == 128 && is_line_kind(kind)))) ? 4 : 1;
+    if (kind == K::Reduce) return 1;
+    if (N == 64) return sizeof(T) == 4 ? BFSM_F32_N64_WAVES : 4;   // fp32 tiles are 33 KiB: more workgroups fit
+    if (N == 128 && is_line_kind(kind)) return 4;
+    return 1;
 }
 
 template <K kind, int N, typename T, class P>
-__global__ void __launch_bounds__((kernel_threads<kind, N>()), (kernel_min_waves<kind, N>())) bfsm_kernel(const P prm) {
+__global__ void __launch_bounds__((kernel_threads<kind, N>()), (kernel_min_waves<kind, N, T>())) bfsm_kernel(const P prm) {
     extern __shared__ __align__(16) unsigned char bfsm_smem[];
     DevCtx ctx{bfsm_smem};
     if constexpr (kind == K::TileFwdReal) body_tile_fwd_real<N, T>(prm, ctx);
