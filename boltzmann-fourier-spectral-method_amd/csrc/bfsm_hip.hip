@@ -2,6 +2,7 @@
 // Built with: hipcc --offload-arch=gfx950 -O3 -fPIC -shared  (see ../Makefile).  No rocFFT / hipFFT / MFMA.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <mutex>
 #include <new>
 #include <string>
@@ -100,6 +101,7 @@ __global__ void __launch_bounds__((kernel_threads<kind, N>()), (kernel_min_waves
 // ---- HIP backend -----------------------------------------------------------------------------------------------
 struct HipBackend {
     hipStream_t stream = nullptr;
+    int device = 0;               // HIP ordinal this backend launches on (set by the handle)
     bool profile = false;
     hipError_t first_error = hipSuccess;
     const char* first_error_where = "";
@@ -142,11 +144,14 @@ struct HipBackend {
         constexpr int threads = kernel_threads<kind, N>();
         constexpr size_t lds = kernel_lds_bytes<kind, N, T>();
         auto fn = bfsm_kernel<kind, N, T, P>;
-        static std::once_flag once;   // one per instantiation
-        std::call_once(once, [&] {
-            if (lds > 48 * 1024)
+        if (lds > 48 * 1024) {   // opt in to a large dynamic-LDS allocation: once per kernel instantiation AND device
+            static std::atomic<unsigned long long> done{0};
+            const unsigned long long bit = 1ull << (device & 63);
+            if (!(done.load(std::memory_order_relaxed) & bit)) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        });
+                done.fetch_or(bit, std::memory_order_relaxed);
+            }
+        }
         Rec rec{pend_kind, pend_bytes, nullptr, nullptr};
         const bool timed = profile && pend_kind >= 0;
         if (timed) { rec.e0 = next_event(); rec.e1 = next_event(); BFSM_NOTE(hipEventRecord(rec.e0, stream)); }
@@ -229,6 +234,7 @@ int bfsm_create(const bfsm_desc* desc, bfsm_handle* out) {
     if (!h) return fail(nullptr, BFSM_ERR_NOMEM, "out of host memory");
     h->desc = *desc;
     h->be.profile = (desc->flags & BFSM_FLAG_PROFILE) != 0;
+    h->be.device = desc->device;
     if (desc->precision == BFSM_F64) {
         h->p64 = new bfsm::Pipeline<double, bfsm::HipBackend>();
         rc = h->p64->init(*desc, &h->be, err);
