@@ -126,7 +126,7 @@ def main():
         if args.max_chunk:
             op.setMaxChunk(args.max_chunk)
         op.setProfiling(profile)
-        op.setExactReductions(exact)
+        op.setExactReductions(exact, hermitian=exact)
         op.initialize()
         return op
 
@@ -230,8 +230,9 @@ def main():
                  "moved_bytes_per_eval_model": cn.moved_bytes_per_eval * world if world == 1 else None,
                  "antipodal_pairs_merged": bool(cn.antipodal_merged),
                  "speedup_vs_headline": (args.steps / el) / evals_per_s,
-                 "note": "BFSM_FLAG_EXACT_REDUCTIONS: antipodal directions merged (exact for the shipped symmetric "
-                         "designs) and one forward FFT per radial-node segment (FFT linearity); parity-tested to 1e-12"}
+                 "note": "BFSM_FLAG_EXACT_REDUCTIONS | BFSM_FLAG_HERMITIAN: antipodal directions merged (exact for the "
+                         "shipped symmetric designs), one forward FFT per radial-node segment (FFT linearity), and "
+                         "only the lx >= 0 planes of A1', A2' computed/stored (f real); parity-tested to 1e-12"}
         ope.destroy()
 
     cpu = None

@@ -7,6 +7,7 @@ BFSM_F64 = 64
 BFSM_F32 = 32
 BFSM_FLAG_PROFILE = 1
 BFSM_FLAG_EXACT_REDUCTIONS = 2
+BFSM_FLAG_HERMITIAN = 4
 KERNEL_NAMES = ("fft_f", "gain_inv", "gain_line", "gain_fwd", "reduce", "tail")
 K_COUNT = len(KERNEL_NAMES)
 

@@ -54,10 +54,13 @@ class HIPBoltzmannOperator:
     def setProfiling(self, on=True):
         self._flags = (self._flags | capi.BFSM_FLAG_PROFILE) if on else (self._flags & ~capi.BFSM_FLAG_PROFILE)
 
-    def setExactReductions(self, on=True):
-        """Opt-in SURVEY 8(f1) reductions (antipodal pairs + one forward FFT per radial node); default off."""
-        f = capi.BFSM_FLAG_EXACT_REDUCTIONS
-        self._flags = (self._flags | f) if on else (self._flags & ~f)
+    def setExactReductions(self, on=True, hermitian=False):
+        """Opt-in SURVEY 8(f1) reductions (antipodal pairs + one forward FFT per radial node); default off.
+        hermitian=True adds BFSM_FLAG_HERMITIAN (only the lx >= 0 planes of A1', A2' are computed and stored)."""
+        f = capi.BFSM_FLAG_EXACT_REDUCTIONS | capi.BFSM_FLAG_HERMITIAN
+        self._flags &= ~f
+        if on:
+            self._flags |= capi.BFSM_FLAG_EXACT_REDUCTIONS | (capi.BFSM_FLAG_HERMITIAN if hermitian else 0)
 
     def getBackendName(self):
         return (self._lib or capi.load_library()).bfsm_backend_name().decode()

@@ -222,6 +222,7 @@ struct GainInvParams {       // KA
     int n_dir;               // directions in this chunk
     int per_group;           // directions handled by one workgroup (blockIdx.y)
     size_t a_bstride;        // elements between consecutive batch members (blockIdx.z) in a1 / a2
+    int planes;              // lx planes stored per direction: N, or N/2 + 1 (indices 0..N/2) in the Hermitian mode
 };
 
 template <typename T>
@@ -277,6 +278,39 @@ struct GainLineAccParams {   // KB', exact-reduction mode: sum over the directio
     int seg0;                // first segment of this chunk
     size_t a_bstride;        // batch strides (elements) of a1 / a2 and of pseg
     size_t pseg_bstride;
+};
+
+// Hermitian mode (f real): only the planes lx = 0 .. N/2 of A1', A2' are computed and stored.  For idx > N/2
+//   A'[idx](y,z) = conj(A'[N - idx](y,z)) + (-1)^y R1[idx](z) + (-1)^z R2[idx](y),
+// where R1 / R2 are 1-D inverse transforms of the Nyquist row ly = -N/2 / column lz = -N/2 of
+//   phx[idx] * f_hat[idx] / G * (phy (x) phz - phy' (x) phz'),   phy', phz' = the tables with their Nyquist entry
+// conjugated (the only modes whose phase is not Hermitian-compatible).  Exact up to rounding.
+template <typename T>
+struct NyqRowsParams {       // KN: R[slot][sign][kind][j][N], j = idx - (N/2 + 1), kind 0: R1 (over z), 1: R2 (over y)
+    const cx<T>* fhat;       // [lx][lz][ly]
+    cx<T>* r;
+    const cx<T>* phx;
+    const cx<T>* phy;
+    const cx<T>* phz;
+    const cx<T>* tw;
+    long long dir0;          // shard-local index of the chunk's first direction
+    size_t r_bstride;        // batch stride (elements) of r
+};
+
+template <typename T>
+struct GainLineAccHParams {  // KB' in the Hermitian mode
+    const cx<T>* a1;         // [slot][N/2 + 1 planes][y][z]
+    const cx<T>* a2;
+    const cx<T>* r;          // Nyquist rows, layout of NyqRowsParams::r
+    cx<T>* pseg;             // [segment][x][y][z]
+    const T* dirw;
+    const Segment* segs;
+    const cx<T>* tw;
+    long long dir0;
+    int seg0;
+    size_t a_bstride;
+    size_t pseg_bstride;
+    size_t r_bstride;
 };
 
 template <typename T>
@@ -402,7 +436,7 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
             v[m] = conj ? cmulc(fh[m], ph) : cmul(fh[m], ph);   // conj(alpha1) f_hat / G  :  alpha1 f_hat / G
         }
         fft_tile<N, +1, T>(v, lds, p, u, twr, ctx);
-        cx<T>* dst = (conj ? prm.a2 : prm.a1) + bz * prm.a_bstride + ((size_t)d * N + lxi) * N * N;
+        cx<T>* dst = (conj ? prm.a2 : prm.a1) + bz * prm.a_bstride + ((size_t)d * prm.planes + lxi) * N * N;
 #pragma unroll
         for (int m = 0; m < E; ++m) ctx.st_stream(dst + (size_t)(u + TT * m) * N + p, v[m]);  // [y = u + T m][z = p]
     }
@@ -469,6 +503,122 @@ BFSM_HD void body_gain_line_acc(const GainLineAccParams<T>& prm, Ctx& ctx) {
     }
     fft_line_np<N, NPL, -1, T>(acc, lds, p, u, twr, ctx);
     const size_t obase = (size_t)ctx.bz() * prm.pseg_bstride + (size_t)(prm.seg0 + ctx.by()) * N * N * N + row;
+#pragma unroll
+    for (int m = 0; m < E; ++m) prm.pseg[obase + (size_t)(u + TT * m) * N * N] = acc[m];
+}
+
+// KN (Hermitian mode).  grid = (column blocks, 2 * directions of the chunk, batch).  One column = one (kind, j):
+// the 1-D inverse transform of the Nyquist row (kind 0: ly = -N/2, running over lz -> z) or column (kind 1:
+// lz = -N/2, running over ly -> y, corner excluded) of plane idx = N/2 + 1 + j, for the sign by & 1.
+template <int N, typename T, class Ctx>
+BFSM_HD void body_nyq_rows(const NyqRowsParams<T>& prm, Ctx& ctx) {
+    constexpr int E = Wg<N>::E, TT = Wg<N>::T, NPL = Wg<N>::NPL, NQ = N / 2 - 1, H = N / 2;
+    const int tid = ctx.tid(), p = tid % NPL, u = ctx.uniform(tid / NPL, NPL);
+    cx<T>* lds = ctx.template lds<cx<T>>();
+    cx<T> twr[E - 1];
+    load_twiddles<N, T>(twr, prm.tw, u, ctx);
+    const int c = ctx.bx() * NPL + p;              // column
+    const bool live = c < 2 * NQ;
+    const int kind = live ? c / NQ : 0, j = live ? c % NQ : 0;
+    const int idx = H + 1 + j;
+    const int dslot = ctx.by() >> 1;
+    const bool conj = (ctx.by() & 1) != 0;
+    const size_t b = (size_t)(prm.dir0 + dslot);
+    const cx<T> px = prm.phx[b * N + idx];
+    const cx<T> pyN = ctx.ldc(prm.phy + b * N + H), pzN = ctx.ldc(prm.phz + b * N + H);
+    const cx<T>* fh = prm.fhat + (size_t)ctx.bz() * N * N * N + (size_t)idx * N * N;
+    cx<T> v[E];
+#pragma unroll
+    for (int m = 0; m < E; ++m) {
+        const int n = u + TT * m;
+        cx<T> f, br;
+        if (kind == 0) {          // row ly = -N/2: f_hat[idx][lz = n][ly = H]
+            f = fh[(size_t)n * N + H];
+            const cx<T> pz = ctx.ldc(prm.phz + b * N + n);
+            const cx<T> pzP = (n == H) ? cx<T>{pz.x, -pz.y} : pz;
+            br = csub(cmul(pyN, pz), cmulc(pzP, pyN));          // phyN*phz - conj(phyN)*phz'
+        } else {                  // column lz = -N/2: f_hat[idx][lz = H][ly = n], corner belongs to kind 0
+            f = fh[(size_t)H * N + n];
+            const cx<T> py = ctx.ldc(prm.phy + b * N + n);
+            br = (n == H) ? cx<T>{(T)0, (T)0} : cmul(py, cx<T>{(T)0, (T)2 * pzN.y});   // phy*(phzN - conj(phzN))
+        }
+        const cx<T> t = conj ? cmulc(cx<T>{br.x, -br.y}, px) : cmul(px, br);   // conj(px)*conj(br) : px*br
+        v[m] = live ? cmul(f, t) : cx<T>{(T)0, (T)0};
+    }
+    fft_line_np<N, NPL, +1, T>(v, lds, p, u, twr, ctx);
+    if (live) {
+        cx<T>* dst = prm.r + (size_t)ctx.bz() * prm.r_bstride + ((size_t)ctx.by() * 2 * NQ + (size_t)kind * NQ + j) * N;
+#pragma unroll
+        for (int m = 0; m < E; ++m) dst[u + TT * m] = v[m];
+    }
+}
+
+// x-line of A' in the Hermitian mode: rows idx = u + T*m of column col = y*N + z.  Two branch-free steps so that all
+// loads of both arrays issue back to back: (1) raw loads -- m < E/2 are stored planes, m > E/2 mirrored planes,
+// m == E/2 (idx = N/2 + u) the stored Nyquist plane for u == 0 and a mirrored plane otherwise; (2) conjugation of
+// the mirrored rows plus the exact Nyquist terms (-1)^y R1[idx](z) + (-1)^z R2[idx](y).
+template <int N, typename T, class Ctx>
+BFSM_HD void hermitian_line_load(cx<T>* v, const cx<T>* A, int col, int u, Ctx& ctx) {
+    constexpr int E = Wg<N>::E, TT = Wg<N>::T, MS = E / 2;
+    static_assert(TT * MS == N / 2, "split row");
+#pragma unroll
+    for (int m = 0; m < E; ++m) {
+        const int idx = u + TT * m;
+        const int plane = (m < MS) ? idx : ((m > MS || u != 0) ? N - idx : idx);
+        v[m] = A[(size_t)plane * N * N + col];     // each stored row is read twice per iteration: keep it cacheable
+    }
+}
+
+template <int N, typename T, class Ctx>
+BFSM_HD void hermitian_line_fix(cx<T>* v, const cx<T>* R, int y, int z, int u, Ctx& ctx) {
+    constexpr int E = Wg<N>::E, TT = Wg<N>::T, NQ = N / 2 - 1, H = N / 2, MS = E / 2;
+    const T sy = (y & 1) ? (T)-1 : (T)1, sz = (z & 1) ? (T)-1 : (T)1;
+#pragma unroll
+    for (int m = MS; m < E; ++m) {
+        const bool mir = (m > MS) || u != 0;
+        const int j = mir ? u + TT * m - (H + 1) : 0;
+        const cx<T> r1 = R[(size_t)j * N + z];
+        const cx<T> r2 = ctx.ldc(R + (size_t)(NQ + j) * N + y);     // (j, y) are wave-uniform for N >= 64
+        const T k = mir ? (T)1 : (T)0, c = mir ? (T)-1 : (T)1;
+        v[m] = {v[m].x + k * (sy * r1.x + sz * r2.x), c * v[m].y + k * (sy * r1.y + sz * r2.y)};
+    }
+}
+
+// KB' (Hermitian mode).  Same as body_gain_line_acc, but the x-lines are rebuilt from the stored half.
+template <int N, typename T, class Ctx>
+BFSM_HD void body_gain_line_acc_h(const GainLineAccHParams<T>& prm, Ctx& ctx) {
+    constexpr int E = Wg<N>::E, TT = Wg<N>::T, NPL = Wg<N>::NPL, NQ = N / 2 - 1, NH = N / 2 + 1;
+    const int tid = ctx.tid(), p = tid % NPL, u = ctx.uniform(tid / NPL, NPL);
+    cx<T>* lds = ctx.template lds<cx<T>>();
+    cx<T> twr[E - 1];
+    load_twiddles<N, T>(twr, prm.tw, u, ctx);
+    const Segment seg = prm.segs[prm.seg0 + ctx.by()];
+    constexpr int BPR = N / NPL;                               // column blocks per row of N
+    const int y = ctx.bx() / BPR, z = (ctx.bx() % BPR) * NPL + p;   // y is uniform over the workgroup
+    const int col = y * N + z;
+    cx<T> acc[E];
+#pragma unroll
+    for (int m = 0; m < E; ++m) acc[m] = {(T)0, (T)0};
+    for (int d = seg.d0; d < seg.d0 + seg.n; ++d) {
+        const size_t abase = (size_t)ctx.bz() * prm.a_bstride + (size_t)d * NH * N * N;
+        const cx<T>* R = prm.r + (size_t)ctx.bz() * prm.r_bstride + (size_t)d * 4 * NQ * N;
+        cx<T> a[E], b[E];
+        hermitian_line_load<N, T>(a, prm.a1 + abase, col, u, ctx);
+        hermitian_line_load<N, T>(b, prm.a2 + abase, col, u, ctx);
+        hermitian_line_fix<N, T>(a, R, y, z, u, ctx);
+        fft_line_np<N, NPL, +1, T>(a, lds, p, u, twr, ctx);
+        hermitian_line_fix<N, T>(b, R + (size_t)2 * NQ * N, y, z, u, ctx);
+        fft_line_np<N, NPL, +1, T>(b, lds, p, u, twr, ctx);
+        const T w = prm.dirw[prm.dir0 + d];
+#pragma unroll
+        for (int m = 0; m < E; ++m) {
+            const cx<T> pr = cmul(a[m], b[m]);
+            acc[m].x += w * pr.x;
+            acc[m].y += w * pr.y;
+        }
+    }
+    fft_line_np<N, NPL, -1, T>(acc, lds, p, u, twr, ctx);
+    const size_t obase = (size_t)ctx.bz() * prm.pseg_bstride + (size_t)(prm.seg0 + ctx.by()) * N * N * N + col;
 #pragma unroll
     for (int m = 0; m < E; ++m) prm.pseg[obase + (size_t)(u + TT * m) * N * N] = acc[m];
 }

@@ -96,6 +96,8 @@ __global__ void __launch_bounds__((kernel_threads<kind, N>()), (kernel_min_waves
     else if constexpr (kind == K::TailInv) body_tail_inv<N, T>(prm, ctx);
     else if constexpr (kind == K::TailLine) body_tail_line<N, T>(prm, ctx);
     else if constexpr (kind == K::GainLineAcc) body_gain_line_acc<N, T>(prm, ctx);
+    else if constexpr (kind == K::NyqRows) body_nyq_rows<N, T>(prm, ctx);
+    else if constexpr (kind == K::GainLineAccH) body_gain_line_acc_h<N, T>(prm, ctx);
 }
 
 // ---- HIP backend -----------------------------------------------------------------------------------------------

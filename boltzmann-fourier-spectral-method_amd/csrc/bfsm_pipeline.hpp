@@ -40,6 +40,7 @@ struct PlanInfo {
     int sph_eff = 0;
     int weight_mult = 1;
     bool exact_reductions = false;         // BFSM_FLAG_EXACT_REDUCTIONS
+    bool hermitian = false;                // BFSM_FLAG_HERMITIAN: store only the planes lx = 0..N/2 of A1', A2' 
     bool antipodal = false;                // design satisfies sigma_{s+M/2} == -sigma_s and w equal, bit-exactly
     long long full_begin = 0, full_end = 0;  // the shard as given, in full quadrature directions b = r*n_sph + s
     long long dir_begin = 0, dir_end = 0;  // the shard in effective directions
@@ -74,6 +75,10 @@ inline int validate_desc(const bfsm_desc& d, std::string& err) {
     }
     if (d.max_chunk < 0) { err = "max_chunk must be >= 0"; return BFSM_ERR_INVALID; }
     if (d.max_batch < 0 || d.max_batch > 65535) { err = "max_batch must be in [0, 65535]"; return BFSM_ERR_INVALID; }
+    if ((d.flags & BFSM_FLAG_HERMITIAN) && !(d.flags & BFSM_FLAG_EXACT_REDUCTIONS)) {
+        err = "BFSM_FLAG_HERMITIAN is an additional exact reduction: set BFSM_FLAG_EXACT_REDUCTIONS as well";
+        return BFSM_ERR_INVALID;
+    }
     return BFSM_OK;
 }
 
@@ -87,6 +92,7 @@ inline PlanInfo make_plan(const bfsm_desc& d) {
     if (d.dir_begin == 0 && d.dir_end == 0) { p.full_begin = 0; p.full_end = B; }
     else { p.full_begin = d.dir_begin; p.full_end = d.dir_end; }
     p.exact_reductions = (d.flags & BFSM_FLAG_EXACT_REDUCTIONS) != 0;
+    p.hermitian = p.exact_reductions && (d.flags & BFSM_FLAG_HERMITIAN) != 0;
     p.sph_eff = d.n_sph;
     if (p.exact_reductions && d.n_sph % 2 == 0) {
         const int h = d.n_sph / 2;
@@ -209,11 +215,13 @@ HostTables<T> build_tables(const bfsm_desc& d, const PlanInfo& p) {
 }
 
 // Kernel identifiers the backend dispatches on.
-enum class K { TileFwdReal, LineFwd, LineInv, TileFwd, TileInv, GainInv, GainLine, GainFwd, Reduce, TailInv, TailLine, GainLineAcc };
+enum class K { TileFwdReal, LineFwd, LineInv, TileFwd, TileInv, GainInv, GainLine, GainFwd, Reduce, TailInv, TailLine, GainLineAcc,
+               NyqRows, GainLineAccH };
 
 // 1-D (x-axis) kernels take Wg<N>::NPL columns per workgroup, 2-D tile kernels a whole N x N tile.
 constexpr bool is_line_kind(K k) {
-    return k == K::LineFwd || k == K::LineInv || k == K::GainLine || k == K::GainLineAcc || k == K::TailLine;
+    return k == K::LineFwd || k == K::LineInv || k == K::GainLine || k == K::GainLineAcc || k == K::TailLine ||
+           k == K::NyqRows || k == K::GainLineAccH;
 }
 
 // Device-resident state of one handle.  `Backend` supplies:
@@ -244,6 +252,7 @@ struct Pipeline {
     cx<T>* pseg = nullptr;        // [segment][x][y][z]
     Segment* segs_unit = nullptr; // one single-slot segment per pseg entry, same r
     T* ones = nullptr;
+    cx<T>* rnyq = nullptr;        // Hermitian mode: Nyquist rows [slot][sign][kind][N/2-1][N]
     size_t slab_count = 0;
 
     template <typename U>
@@ -255,6 +264,8 @@ struct Pipeline {
         return true;
     }
 
+    int a_planes = 0;        // lx planes of A1' / A2' kept per direction (N, or N/2 + 1 in the Hermitian mode)
+    size_t r_per_dir() const { return (size_t)4 * (plan.N / 2 - 1) * plan.N; }
     int max_batch = 1;       // distributions evaluated per call; scratch scales with it
     size_t cap = 1;          // directions resident at once (largest chunk)
 
@@ -273,8 +284,11 @@ struct Pipeline {
         ok = ok && (tg = (cx<T>*)be->alloc(nb * G * sizeof(cx<T>)));
         ok = ok && (tl = (cx<T>*)be->alloc(nb * G * sizeof(cx<T>)));
         ok = ok && (qhat = (cx<T>*)be->alloc(nb * G * sizeof(cx<T>)));
-        ok = ok && (a1 = (cx<T>*)be->alloc(nb * cap * G * sizeof(cx<T>)));
-        ok = ok && (a2 = (cx<T>*)be->alloc(nb * cap * G * sizeof(cx<T>)));
+        a_planes = plan.hermitian ? plan.N / 2 + 1 : plan.N;
+        const size_t Gp = (size_t)a_planes * plan.N * plan.N;       // elements of A1' / A2' per direction
+        ok = ok && (a1 = (cx<T>*)be->alloc(nb * cap * Gp * sizeof(cx<T>)));
+        ok = ok && (a2 = (cx<T>*)be->alloc(nb * cap * Gp * sizeof(cx<T>)));
+        if (plan.hermitian) ok = ok && (rnyq = (cx<T>*)be->alloc(nb * cap * r_per_dir() * sizeof(cx<T>)));
         ok = ok && (slab = (cx<T>*)be->alloc(nb * nslab * G * sizeof(cx<T>)));
         ok = ok && dev_copy(tw, t.tw) && dev_copy(phx, t.phx) && dev_copy(phy, t.phy) && dev_copy(phz, t.phz);
         ok = ok && dev_copy(dirw, t.dirw) && dev_copy(beta1, t.beta1) && dev_copy(beta2, t.beta2) && dev_copy(segs, plan.segs);
@@ -291,12 +305,12 @@ struct Pipeline {
 
     void destroy() {
         if (!be) return;
-        void* ptrs[] = {fhat, tg, tl, qhat, a1, a2, slab, tw, phx, phy, phz, dirw, beta1, beta2, segs, pseg, segs_unit, ones};
+        void* ptrs[] = {fhat, tg, tl, qhat, a1, a2, slab, tw, phx, phy, phz, dirw, beta1, beta2, segs, pseg, segs_unit, ones, rnyq};
         for (void* p : ptrs) if (p) be->release(p);
         fhat = tg = tl = qhat = a1 = a2 = slab = tw = phx = phy = phz = nullptr;
         dirw = beta1 = beta2 = nullptr;
         segs = nullptr;
-        pseg = nullptr; segs_unit = nullptr; ones = nullptr;
+        pseg = nullptr; segs_unit = nullptr; ones = nullptr; rnyq = nullptr;
     }
 
     double cbytes() const { return (double)sizeof(cx<T>); }
@@ -309,7 +323,9 @@ struct Pipeline {
         const int N = plan.N;
         const double Gc = (double)plan.G() * cbytes() * nb;
         const size_t G = plan.G();
-        const size_t a_bs = cap * G, s_bs = (slab_count ? slab_count : 1) * G;
+        const size_t a_bs = cap * (size_t)a_planes * N * N, s_bs = (slab_count ? slab_count : 1) * G;
+        const size_t r_bs = cap * r_per_dir();
+        const double hfrac = (double)a_planes / N;                 // share of A' actually stored
         {   // F1: f_hat  (CUDABoltzmannOperator.cu:133-140)
             TileFwdRealParams<T> pa{f_dev, tg, tw};
             be->mark(BFSM_K_FFT_F, 1.5 * Gc);
@@ -319,10 +335,13 @@ struct Pipeline {
             be->template launch<K::LineFwd, T>(line_blocks(), nb, 1, pb, N);
         }
         for (const Chunk& c : plan.chunks) {
-            GainInvParams<T> ka{fhat, a1, a2, phx, phy, phz, tw, c.dir0, c.n, c.per_group, a_bs};
-            const int ga = (c.n + c.per_group - 1) / c.per_group;
-            be->mark(BFSM_K_GAIN_INV, 2.0 * c.n * Gc);
-            be->template launch<K::GainInv, T>(N, ga, nb, ka, N);
+            // KA's parallelism is planes x direction groups: keep >= 2 workgroups per CU when only N/2 + 1 planes run
+            const int groups_a = 512 / a_planes > 0 ? 512 / a_planes : 1;   // <= 512 workgroups: one resident wave of them
+            const int per_group_a = (c.n + groups_a - 1) / groups_a;
+            GainInvParams<T> ka{fhat, a1, a2, phx, phy, phz, tw, c.dir0, c.n, per_group_a, a_bs, a_planes};
+            const int ga = (c.n + per_group_a - 1) / per_group_a;
+            be->mark(BFSM_K_GAIN_INV, 2.0 * c.n * Gc * hfrac);
+            be->template launch<K::GainInv, T>(a_planes, ga, nb, ka, N);
             if (!plan.exact_reductions) {
                 GainLineParams<T> kb{a1, a2, tw, a_bs};
                 be->mark(BFSM_K_GAIN_LINE, 3.0 * c.n * Gc);
@@ -330,10 +349,18 @@ struct Pipeline {
                 GainFwdParams<T> kc{a1, slab, dirw, segs, tw, c.dir0, c.seg0, a_bs, s_bs};
                 be->mark(BFSM_K_GAIN_FWD, 1.0 * c.n * Gc);
                 be->template launch<K::GainFwd, T>(N, c.n_seg, nb, kc, N);
-            } else {
+            } else if (!plan.hermitian) {
                 GainLineAccParams<T> kb{a1, a2, pseg, dirw, segs, tw, c.dir0, c.seg0, a_bs, s_bs};
                 be->mark(BFSM_K_GAIN_LINE, (2.0 * c.n + c.n_seg) * Gc);
                 be->template launch<K::GainLineAcc, T>(line_blocks(), c.n_seg, nb, kb, N);
+            } else {
+                NyqRowsParams<T> kn{fhat, rnyq, phx, phy, phz, tw, c.dir0, r_bs};
+                const int npl = N > 64 ? 64 : N, ncol = 2 * (N / 2 - 1);
+                be->mark(BFSM_K_GAIN_INV, 0.0);
+                be->template launch<K::NyqRows, T>((ncol + npl - 1) / npl, 2 * c.n, nb, kn, N);
+                GainLineAccHParams<T> kb{a1, a2, rnyq, pseg, dirw, segs, tw, c.dir0, c.seg0, a_bs, s_bs, r_bs};
+                be->mark(BFSM_K_GAIN_LINE, (2.0 * c.n * hfrac + c.n_seg) * Gc);
+                be->template launch<K::GainLineAccH, T>(line_blocks(), c.n_seg, nb, kb, N);
             }
         }
         if (plan.exact_reductions && slab_count) {   // one forward tile pass per segment, all chunks at once
@@ -391,7 +418,8 @@ inline double moved_bytes_per_eval(const PlanInfo& p) {
     const double c = p.precision == BFSM_F64 ? 16.0 : 8.0;
     const double G = (double)p.G(), n = (double)p.n_dirs(), sg = (double)p.segs.size();
     if (!p.exact_reductions) return (6.0 * n + 2.0 * sg + 9.0) * G * c;
-    return (4.0 * n + 4.0 * sg + 9.0) * G * c;
+    const double h = p.hermitian ? (double)(p.N / 2 + 1) / p.N : 1.0;
+    return (4.0 * n * h + 4.0 * sg + 9.0) * G * c;
 }
 
 }  // namespace bfsm

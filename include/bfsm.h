@@ -49,7 +49,12 @@ enum {
      *  (ii) FFT linearity: the products of all directions of a radial node are summed in physical space and
      *       forward-transformed once, instead of one forward FFT per direction.
      * The default (flag clear) evaluates every direction with its own three FFTs, like the reference. */
-    BFSM_FLAG_EXACT_REDUCTIONS = 2
+    BFSM_FLAG_EXACT_REDUCTIONS = 2,
+    /* Additional exact reduction on top of BFSM_FLAG_EXACT_REDUCTIONS (invalid without it): f is real, so the
+     * half-transformed arrays satisfy A'[-lx] = conj A'[lx] up to the three Nyquist planes; only the planes
+     * lx = 0 .. N/2 are computed and stored, the rest is rebuilt by conjugation plus exact rank-one Nyquist terms
+     * (the r2c / c2r saving the reference lists as future work, CUDABoltzmannOperator.cu:36). */
+    BFSM_FLAG_HERMITIAN = 4
 };
 
 typedef struct bfsm_plan* bfsm_handle;

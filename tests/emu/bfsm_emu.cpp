@@ -146,6 +146,8 @@ struct EmuBackend {
         else if constexpr (kind == K::TailInv) body_tail_inv<N, T>(prm, ctx);
         else if constexpr (kind == K::TailLine) body_tail_line<N, T>(prm, ctx);
         else if constexpr (kind == K::GainLineAcc) body_gain_line_acc<N, T>(prm, ctx);
+        else if constexpr (kind == K::NyqRows) body_nyq_rows<N, T>(prm, ctx);
+        else if constexpr (kind == K::GainLineAccH) body_gain_line_acc_h<N, T>(prm, ctx);
     }
 
     template <bfsm::K kind, int N, typename T, class P>

@@ -190,3 +190,41 @@ def test_batch_of_distributions(oracle, flags):
         assert np.array_equal(Qb[i], Qi)
         Qo = oracle.collide(fs[i], gl, sph, GAMMA, B_GAMMA, L)
         assert np.abs(Qb[i] - Qo).max() <= 1e-12 * np.abs(Qo).max()
+
+
+HERMITIAN = 4   # BFSM_FLAG_HERMITIAN (only together with EXACT)
+
+
+@pytest.mark.parametrize("nv,n_gl,n_sph,max_chunk", [(16, 3, 12, 0), (16, 3, 12, 5), (32, 2, 6, 0)])
+def test_hermitian_reduction_matches_oracle(oracle, nv, n_gl, n_sph, max_chunk):
+    """f real => A'[-lx] = conj A'[lx] + exact rank-one Nyquist terms: only the planes lx = 0..N/2 are computed and
+    stored.  The perturbed input has energy in all three Nyquist planes, so a wrong correction shows at 1e-3."""
+    f, _, L, _ = oracle.bkw(nv)
+    f = oracle.perturbed_input(f)
+    gl = oracle.gauss_legendre(n_gl, 0.0, R)
+    sph = oracle.spherical_design(n_sph)
+    Qo, qo = oracle.collide(f, gl, sph, GAMMA, B_GAMMA, L, return_qhat=True)
+    Q, qhat = E.collide(f, gl, sph, GAMMA, B_GAMMA, L, 64, max_chunk=max_chunk, flags=EXACT | HERMITIAN)
+    assert np.abs(qhat - qo).max() <= 1e-12 * np.abs(qo).max()
+    assert np.abs(Q - Qo).max() <= 1e-12 * np.abs(Qo).max()
+
+
+def test_hermitian_needs_exact_flag():
+    with pytest.raises(ValueError):
+        E.plan(16, 2, 6, 64, flags=HERMITIAN)
+
+
+def test_hermitian_batch_and_shards(oracle):
+    f0, _, L, _ = oracle.bkw(16)
+    fs = np.stack([oracle.perturbed_input(f0, seed=s) for s in (5, 6)])
+    gl = oracle.gauss_legendre(3, 0.0, R)
+    sph = oracle.spherical_design(12)
+    Qb = E.collide_batch(fs, gl, sph, GAMMA, B_GAMMA, L, max_chunk=7, flags=EXACT | HERMITIAN)
+    for i in range(2):
+        Qo, whole = oracle.collide(fs[i], gl, sph, GAMMA, B_GAMMA, L, return_qhat=True)
+        assert np.abs(Qb[i] - Qo).max() <= 1e-12 * np.abs(Qo).max()
+    parts = 0
+    for rng_ in ((0, 13), (13, 36)):
+        _, qh = E.collide(fs[1], gl, sph, GAMMA, B_GAMMA, L, 64, dir_range=rng_, want_Q=False, flags=EXACT | HERMITIAN)
+        parts = parts + qh
+    assert np.abs(parts - whole).max() <= 1e-12 * np.abs(whole).max()

@@ -24,7 +24,7 @@ def torch_cuda():
 
 
 def _make(bfsm, nv, n_gl, n_sph, precision=64, shard=None, max_chunk=0, profile=False, exact=False, gamma=None,
-          b_gamma=None, max_batch=0):
+          b_gamma=None, max_batch=0, hermitian=False):
     c = dict(bfsm.reference_constants())
     if gamma is not None:
         c["gamma"], c["b_gamma"] = gamma, b_gamma
@@ -37,7 +37,7 @@ def _make(bfsm, nv, n_gl, n_sph, precision=64, shard=None, max_chunk=0, profile=
     if max_chunk:
         op.setMaxChunk(max_chunk)
     op.setProfiling(profile)
-    op.setExactReductions(exact)
+    op.setExactReductions(exact or hermitian, hermitian=hermitian)
     op.setMaxBatch(max_batch)
     op.initialize()
     return op
@@ -405,3 +405,30 @@ def test_cpp_multi_gpu_driver_on_one_device(torch_cuda):
     got = {k: float(re.search(k + r" error: (\S+)", out.stdout).group(1)) for k in ("L1", "L2", "Linf")}
     for k in ("L1", "L2", "Linf"):
         assert got[k] == pytest.approx(row[k], rel=2e-5), (k, got)
+
+
+@pytest.mark.parametrize("nv,n_gl,n_sph", [(16, 8, 32), (32, 8, 48), (64, 2, 12)])
+def test_hermitian_reduction_matches_oracle(torch_cuda, oracle, nv, n_gl, n_sph):
+    """BFSM_FLAG_HERMITIAN (planes lx = 0..N/2 only + exact Nyquist terms) against the oracle on an input with energy
+    in all Nyquist planes; also the fp32 variant at N = 128."""
+    import bfsm
+    f_h = bfsm.perturbed_input(bfsm.bkw_solution(nv)[0])
+    op = _make(bfsm, nv, n_gl, n_sph, hermitian=True)
+    got = _collide(torch_cuda, op, f_h)
+    op.destroy()
+    ref = _oracle(oracle, f_h, n_gl, n_sph)
+    assert np.abs(got - ref).max() <= TOL64 * np.abs(ref).max()
+
+
+def test_hermitian_full_size(torch_cuda, oracle):
+    import bfsm
+    torch = torch_cuda
+    nv, n_gl, n_sph = 64, 16, 48
+    f_h = bfsm.perturbed_input(bfsm.bkw_solution(nv)[0])
+    a = _collide(torch, _make(bfsm, nv, n_gl, n_sph), f_h)
+    b = _collide(torch, _make(bfsm, nv, n_gl, n_sph, hermitian=True), f_h)
+    assert np.abs(a - b).max() <= 1e-13 * np.abs(a).max()
+    f128 = bfsm.perturbed_input(bfsm.bkw_solution(128)[0])
+    ref = _oracle(oracle, f128, 2, 12)
+    got = _collide(torch, _make(bfsm, 128, 2, 12, 32, hermitian=True), f128)
+    assert np.abs(got - ref).max() <= TOL32 * np.abs(ref).max()
