@@ -346,7 +346,8 @@ void* bfsm_qhat_buffer(bfsm_handle h, size_t* n_elems, int* precision) {
 int bfsm_fft3d(bfsm_handle h, void* data_dev, int batch, int sign) {
     int rc = enter(h, nullptr);
     if (rc) return rc;
-    if (!data_dev || batch < 1 || (sign != 1 && sign != -1)) return fail(h, BFSM_ERR_INVALID, "bad fft3d argument");
+    if (!data_dev || batch < 1 || batch > 65535 || (sign != 1 && sign != -1))
+        return fail(h, BFSM_ERR_INVALID, "bad fft3d argument (null data, batch outside [1, 65535] or sign not +-1)");
     if (h->p64) h->p64->fft3d((bfsm::cx<double>*)data_dev, batch, sign);
     else h->p32->fft3d((bfsm::cx<float>*)data_dev, batch, sign);
     rc = check_hip(h, "bfsm_fft3d");

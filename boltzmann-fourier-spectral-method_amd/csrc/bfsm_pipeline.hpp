@@ -73,7 +73,7 @@ inline int validate_desc(const bfsm_desc& d, std::string& err) {
     if (!(d.dir_begin == 0 && d.dir_end == 0) && (d.dir_begin < 0 || d.dir_end > B || d.dir_begin > d.dir_end)) {
         err = "direction shard out of range"; return BFSM_ERR_INVALID;
     }
-    if (d.max_chunk < 0) { err = "max_chunk must be >= 0"; return BFSM_ERR_INVALID; }
+    if (d.max_chunk < 0 || d.max_chunk > 16384) { err = "max_chunk must be in [0, 16384] (it is a grid dimension)"; return BFSM_ERR_INVALID; }
     if (d.max_batch < 0 || d.max_batch > 65535) { err = "max_batch must be in [0, 65535]"; return BFSM_ERR_INVALID; }
     if ((d.flags & BFSM_FLAG_HERMITIAN) && !(d.flags & BFSM_FLAG_EXACT_REDUCTIONS)) {
         err = "BFSM_FLAG_HERMITIAN is an additional exact reduction: set BFSM_FLAG_EXACT_REDUCTIONS as well";

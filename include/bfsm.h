@@ -153,7 +153,7 @@ int bfsm_synchronize(bfsm_handle h);
  * CUDABoltzmannOperator.cu:88-100; used by the FFT unit tests that mirror cufft_benchmark.cu:150-207).
  * data_dev: batch * G interleaved complex of the handle's precision, transformed in place, unnormalised.
  * sign -1 = forward: physical [x][y][z] in, spectral-transposed [lx][lz][ly] out (the library's spectral layout);
- * sign +1 = backward: [lx][lz][ly] in, [x][y][z] out.  batch <= the handle's max_chunk. */
+ * sign +1 = backward: [lx][lz][ly] in, [x][y][z] out.  1 <= batch <= 65535 (one grid dimension). */
 int bfsm_fft3d(bfsm_handle h, void* data_dev, int batch, int sign);
 
 int bfsm_get_counters(bfsm_handle h, bfsm_counters* out);
