@@ -432,3 +432,23 @@ def test_hermitian_full_size(torch_cuda, oracle):
     ref = _oracle(oracle, f128, 2, 12)
     got = _collide(torch, _make(bfsm, 128, 2, 12, 32, hermitian=True), f128)
     assert np.abs(got - ref).max() <= TOL32 * np.abs(ref).max()
+
+
+def test_bench_two_ranks_rehearsal(torch_cuda):
+    """bench.py under torch.distributed.run with 2 ranks.  A one-GPU box cannot host two RCCL ranks, so the
+    rehearsal backend (gloo, both ranks on device 0) is used: same sharding, same bfsm.sharded_step, same timing and
+    JSON code path as the 8-GPU run; only the collective's transport differs."""
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, BFSM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
+                          "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "cfg2", "--no-roofline"],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "strong"
+    assert d["config"]["directions_per_gpu"] == 192 and d["cpu_baseline"] is None
+    assert d["exact_reductions"]["value"] > 0
