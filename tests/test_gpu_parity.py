@@ -452,3 +452,22 @@ def test_bench_two_ranks_rehearsal(torch_cuda):
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "strong"
     assert d["config"]["directions_per_gpu"] == 192 and d["cpu_baseline"] is None
     assert d["exact_reductions"]["value"] > 0
+
+
+def test_cpp_relaxation_driver(torch_cuda):
+    """host/bkw_relax_hip.cpp: the C++ time-stepping caller (SSP-RK3, f resident on the device) tracks the exact BKW
+    solution at N=32 to the grid's spectral accuracy and conserves mass to truncation level."""
+    import re
+    import subprocess
+    pkg = os.path.join(os.path.dirname(HERE), "boltzmann-fourier-spectral-method_amd")
+    exe = os.path.join(pkg, "bkw_relax_hip")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", pkg, "-s", "bkw_relax_hip"])
+    out = subprocess.run([exe, "--Nv", "32", "--Ngl", "16", "--Ns", "32", "--steps", "10", "--exact-reductions",
+                          "--design-dir", os.path.join(pkg, "data", "sph_design")],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    l2 = float(re.search(r"L2 error vs exact BKW: (\S+)", out.stdout).group(1))
+    mass = float(re.search(r"relative mass drift: (\S+)", out.stdout).group(1))
+    h = re.search(r"entropy: (\S+) -> (\S+)", out.stdout)
+    assert l2 < 2e-4 and mass < 5e-4 and float(h.group(2)) < float(h.group(1))
