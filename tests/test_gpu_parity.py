@@ -471,3 +471,16 @@ def test_cpp_relaxation_driver(torch_cuda):
     mass = float(re.search(r"relative mass drift: (\S+)", out.stdout).group(1))
     h = re.search(r"entropy: (\S+) -> (\S+)", out.stdout)
     assert l2 < 2e-4 and mass < 5e-4 and float(h.group(2)) < float(h.group(1))
+
+
+def test_hip_matches_committed_q_fixtures(torch_cuda):
+    """HIP path against the committed data fixtures (config 1: N=16, M_gl=8, 32-point design), all three modes."""
+    import bfsm
+    f0 = bfsm.bkw_solution(16)[0]
+    for name, f_h in (("q_cfg1_bkw.npy", f0), ("q_cfg1_random.npy", bfsm.perturbed_input(f0))):
+        want = np.load(os.path.join(HERE, "golden", name))
+        for kw in ({}, {"exact": True}, {"hermitian": True}):
+            op = _make(bfsm, 16, 8, 32, **kw)
+            got = _collide(torch_cuda, op, f_h)
+            op.destroy()
+            assert np.abs(got - want).max() <= TOL64 * np.abs(want).max(), (name, kw)

@@ -124,3 +124,14 @@ def test_design_tables_bit_identical_to_reference_data(oracle):
         ref = np.array([[float(v) for v in ln.split()] for ln in open(p) if ln.strip()])
         x, y, z, _ = oracle.spherical_design(n)
         assert np.array_equal(ref, np.stack([x, y, z], axis=1))
+
+
+def test_oracle_reproduces_committed_q_fixtures(oracle):
+    """Data-only regression guard: tests/golden/q_cfg1_*.npy were written by tests/golden/make_fixtures.py."""
+    f, _, L, _ = oracle.bkw(16)
+    gl = oracle.gauss_legendre(8, 0.0, R)
+    sph = oracle.spherical_design(32)
+    for name, inp in (("q_cfg1_bkw.npy", f), ("q_cfg1_random.npy", oracle.perturbed_input(f))):
+        want = np.load(os.path.join(HERE, "golden", name))
+        got = oracle.collide(inp, gl, sph, GAMMA, B_GAMMA, L)
+        assert np.abs(got - want).max() <= 1e-14 * np.abs(want).max()      # thread count / libm independent
