@@ -604,8 +604,8 @@ BFSM_HD void body_gain_line_acc_h(const GainLineAccHParams<T>& prm, Ctx& ctx) {
         const cx<T>* R = prm.r + (size_t)ctx.bz() * prm.r_bstride + (size_t)d * 4 * NQ * N;
         cx<T> a[E], b[E];
         hermitian_line_load<N, T>(a, prm.a1 + abase, col, u, ctx);
-        hermitian_line_load<N, T>(b, prm.a2 + abase, col, u, ctx);
         hermitian_line_fix<N, T>(a, R, y, z, u, ctx);
+        hermitian_line_load<N, T>(b, prm.a2 + abase, col, u, ctx);     // in flight while a is transformed
         fft_line_np<N, NPL, +1, T>(a, lds, p, u, twr, ctx);
         hermitian_line_fix<N, T>(b, R + (size_t)2 * NQ * N, y, z, u, ctx);
         fft_line_np<N, NPL, +1, T>(b, lds, p, u, twr, ctx);
