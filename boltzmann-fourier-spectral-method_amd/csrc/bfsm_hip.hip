@@ -76,6 +76,7 @@ template <K kind, int N, typename T>
 constexpr int kernel_min_waves() {
     if (kind == K::Reduce) return 1;
     if (N == 64) return sizeof(T) == 4 ? BFSM_F32_N64_WAVES : 4;   // fp32 tiles are 33 KiB: more workgroups fit
+    if (N == 32) return 4;                                         // 128-thread workgroups: 8 per CU at <= 128 VGPRs
     if (N == 128 && is_line_kind(kind)) return 4;
     return 1;
 }
