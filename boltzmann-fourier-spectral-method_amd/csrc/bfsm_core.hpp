@@ -214,11 +214,11 @@ struct GainInvParams {       // KA
     const cx<T>* fhat;       // [lx][lz][ly]
     cx<T>* a1;               // [slot][lx][y][z]
     cx<T>* a2;
-    const cx<T>* phx;        // [B][N] phase tables, exp(i*theta) factors; phx carries the 1/G scale
+    const cx<T>* phx;        // [shard directions][N] phase tables, exp(i*theta) factors; phx carries the 1/G scale
     const cx<T>* phy;
     const cx<T>* phz;
     const cx<T>* tw;
-    long long dir0;          // global index of the chunk's first direction (b = r*M_sph + s)
+    long long dir0;          // shard-local index of the chunk's first direction (tables are shard-local)
     int n_dir;               // directions in this chunk
     int per_group;           // directions handled by one workgroup (blockIdx.y)
     size_t a_bstride;        // elements between consecutive batch members (blockIdx.z) in a1 / a2
