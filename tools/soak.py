@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Soak test: repeated evaluations are bitwise reproducible; create/destroy cycles do not leak device memory."""
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "boltzmann-fourier-spectral-method_amd"))
+import numpy as np
+import torch
+import bfsm
+
+c = bfsm.reference_constants()
+nv, n_gl, n_sph = 64, 16, 48
+f = torch.from_numpy(bfsm.perturbed_input(bfsm.bkw_solution(nv)[0])).cuda()
+Q = torch.empty_like(f)
+for mode in ((False, False), (True, False), (True, True)):
+    op = bfsm.HIPBoltzmannOperator(bfsm.GaussLegendreQuadrature(n_gl, 0, c["R"]), bfsm.SphericalDesign(n_sph), nv, nv, nv,
+                                   c["gamma"], c["b_gamma"], c["L"])
+    op.setExactReductions(mode[0], hermitian=mode[1])
+    op.initialize()
+    op(Q, f)
+    first = Q.clone()
+    s = torch.cuda.current_stream().cuda_stream
+    bad = 0
+    for i in range(1, 601):
+        op.computeCollisionAsync(Q, f, s)
+        if i % 100 == 0:
+            torch.cuda.synchronize()
+            bad += int(not torch.equal(Q, first))
+    torch.cuda.synchronize()
+    print("mode exact=%s hermitian=%s: 600 evaluations, %d mismatching snapshots" % (mode[0], mode[1], bad))
+    op.destroy()
+torch.cuda.synchronize()
+free0 = torch.cuda.mem_get_info()[0]
+for i in range(20):
+    op = bfsm.HIPBoltzmannOperator(bfsm.GaussLegendreQuadrature(8, 0, c["R"]), bfsm.SphericalDesign(48), 32, 32, 32,
+                                   c["gamma"], c["b_gamma"], c["L"])
+    op.setExactReductions(i % 2 == 1, hermitian=i % 4 == 3)
+    op.setMaxBatch(1 + i % 3)
+    op.initialize()
+    op.destroy()
+torch.cuda.synchronize()
+free1 = torch.cuda.mem_get_info()[0]
+print("device memory free before/after 20 create/destroy cycles: %.1f / %.1f MiB (delta %.1f MiB)" % (free0 / 2**20, free1 / 2**20, (free0 - free1) / 2**20))
