@@ -6,13 +6,18 @@ host-emulated operator in the world-size-2 gloo tests.  `qhat` is a tensor view 
 """
 
 
-def sharded_step(op, qhat, Q, f, dist=None, stream=0, reduce_spectral=False):
+def sharded_step(op, qhat, Q, f, dist=None, stream=0, reduce_spectral=False, async_op=False):
     """One collision evaluation on this rank's shard.  With dist=None it degenerates to the single-device path.
 
     Default route (reduce_spectral=False): every rank inverse-transforms its own partial Q_gain_hat (the transform
     is linear), rank 0 also subtracts the loss term, and the ONE collective sums the real Q (G doubles: half the
     bytes of Q_hat, and nothing runs after the collective).  reduce_spectral=True is the textbook route: sum the
     complex Q_gain_hat buffers (2G reals), then run the tail on every rank.
+
+    async_op=True (default route only) returns the collective's work handle instead of waiting for it: nothing of
+    this rank's next evaluation depends on the summed Q, so a caller that alternates between two Q buffers can let
+    the all-reduce of evaluation i run (on RCCL's own stream) under the gain kernels of evaluation i+1, and calls
+    handle.wait() before it reads or reuses that Q.  Returns None when there is nothing to wait for.
     """
     multi = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
     op.gainPartial(f, stream)
@@ -23,7 +28,9 @@ def sharded_step(op, qhat, Q, f, dist=None, stream=0, reduce_spectral=False):
         op.finish(Q, f, stream)
     else:
         op.finishPartial(Q, f, dist.get_rank() == 0, stream)
-        dist.all_reduce(Q)               # the single collective of an evaluation (sum)
+        work = dist.all_reduce(Q, async_op=async_op)      # the single collective of an evaluation (sum)
+        return work if async_op else None
+    return None
 
 
 def device_view(torch, ptr, n, precision):

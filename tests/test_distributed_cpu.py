@@ -40,7 +40,21 @@ def _worker(rank, world, port, nv, n_gl, n_sph, out_dir, spectral):
     op = E.EmuOperator(nv, gl, sph, c["gamma"], c["b_gamma"], c["L"], dir_range=shard, max_chunk=5)
     f = torch.from_numpy(f_h.reshape(-1).copy())
     Q = torch.empty_like(f)
-    bfsm.sharded_step(op, op.qhat, Q, f, dist, reduce_spectral=spectral)
+    if spectral == "overlap":
+        # bench.py's N>1 loop: two result buffers, the all-reduce of evaluation i left in flight while evaluation i+1
+        # is queued; every buffer is waited for before it is reused / read
+        Qs, pending = (Q, torch.empty_like(f)), [None, None]
+        for i in range(3):
+            k = i & 1
+            if pending[k] is not None:
+                pending[k].wait()
+            pending[k] = bfsm.sharded_step(op, op.qhat, Qs[k], f, dist, async_op=True)
+            assert pending[k] is not None
+        for w in pending:
+            w.wait()
+        assert torch.equal(Qs[0], Qs[1])
+    else:
+        assert bfsm.sharded_step(op, op.qhat, Q, f, dist, reduce_spectral=spectral) is None
     # every rank must hold the same, complete answer
     ref = O.collide(f_h, gl, sph, c["gamma"], c["b_gamma"], c["L"])
     err = float(np.abs(Q.numpy().reshape(ref.shape) - ref).max() / np.abs(ref).max())
@@ -51,7 +65,7 @@ def _worker(rank, world, port, nv, n_gl, n_sph, out_dir, spectral):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,spectral", [(2, False), (3, False), (2, True)])
+@pytest.mark.parametrize("world,spectral", [(2, False), (3, False), (2, True), (2, "overlap")])
 def test_sharded_step_over_gloo(tmp_path, world, spectral):
     import torch.multiprocessing as mp
     nv, n_gl, n_sph = 16, 3, 12
