@@ -38,9 +38,28 @@ WORKLOADS = {
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling there: 6290 GB/s
 
 
+def usable_cpus():
+    """CPUs this process can actually run on at once: the affinity mask, capped by the cgroup CPU quota (a GPU box
+    shows all 256 hardware threads of the host but grants one GPU's share of them: cpu.max = 16 CPUs)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(w, seconds_target=15.0):
     """The oracle (CPU restatement of the reference's FFTW path, kind "port") timed on this box's host cores on a
-    bounded sample: the first n_sample directions of the same workload, all OpenMP threads."""
+    bounded sample: the first n_sample directions of the same workload, one OpenMP thread per usable CPU."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
     import oracle as O
@@ -50,23 +69,23 @@ def cpu_baseline(w, seconds_target=15.0):
     gl = O.gauss_legendre(w["n_gl"], 0.0, c["R"])
     sph = O.spherical_design(w["n_sph"])
     B = w["n_gl"] * w["n_sph"]
-    threads = O.lib().bfsm_oracle_threads()
+    threads = max(1, min(O.lib().bfsm_oracle_threads(), usable_cpus()))
     n = min(B, max(2 * threads, 8))
     t0 = time.perf_counter()
-    O.collide(f_h, gl, sph, c["gamma"], c["b_gamma"], c["L"], dir_range=(0, n))
+    O.collide(f_h, gl, sph, c["gamma"], c["b_gamma"], c["L"], dir_range=(0, n), threads=threads)
     t1 = time.perf_counter() - t0
     # scale the sample up once if it was very short, to get ~seconds_target of CPU work
     if t1 < seconds_target / 4 and n < B:
         n2 = int(min(B, max(n, n * (seconds_target / max(t1, 1e-3)) * 0.8)))
         n2 = max(threads, (n2 // threads) * threads)
         t0 = time.perf_counter()
-        O.collide(f_h, gl, sph, c["gamma"], c["b_gamma"], c["L"], dir_range=(0, n2))
+        O.collide(f_h, gl, sph, c["gamma"], c["b_gamma"], c["L"], dir_range=(0, n2), threads=threads)
         t1, n = time.perf_counter() - t0, n2
     evals_per_s = (n / B) / t1
     return {"value": evals_per_s, "unit": "evals/s", "cores": threads, "kind": "port",
             "sample": f"oracle/bfsm_oracle.c (own radix-2 FFT, fp64), first {n} of {B} directions of the same workload "
-                      f"in {t1:.2f} s on {threads} OpenMP threads, extrapolated linearly to B; FFTW3 is not installed "
-                      f"in this image"}
+                      f"in {t1:.2f} s on {threads} OpenMP threads (= the CPUs this process may use: affinity mask capped "
+                      f"by the cgroup quota), extrapolated linearly to B; FFTW3 is not installed in this image"}
 
 
 def main():
