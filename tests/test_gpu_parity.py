@@ -484,3 +484,31 @@ def test_hip_matches_committed_q_fixtures(torch_cuda):
             got = _collide(torch_cuda, op, f_h)
             op.destroy()
             assert np.abs(got - want).max() <= TOL64 * np.abs(want).max(), (name, kw)
+
+
+@pytest.mark.parametrize("exact", [False, True])
+def test_evaluation_is_graph_capturable(torch_cuda, exact):
+    """The async entry points only enqueue kernels (no allocation, no synchronisation, no attribute calls after the
+    first evaluation), so a caller can capture an evaluation in a HIP graph and replay it on new contents of f."""
+    import bfsm
+    torch = torch_cuda
+    nv, n_gl, n_sph = 32, 4, 12
+    op = _make(bfsm, nv, n_gl, n_sph, exact=exact, hermitian=exact)
+    f0 = bfsm.perturbed_input(bfsm.bkw_solution(nv)[0])
+    f = torch.from_numpy(f0).cuda()
+    Q, Qg = torch.empty_like(f), torch.zeros_like(f)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        op.computeCollisionAsync(Qg, f, side.cuda_stream)          # first call outside the capture
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        op.computeCollisionAsync(Qg, f, torch.cuda.current_stream().cuda_stream)
+    for scale in (1.0, 0.5):
+        f.copy_(torch.from_numpy(f0 * scale))
+        Qg.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        op(Q, f)
+        assert torch.equal(Q, Qg)
+    op.destroy()
