@@ -133,35 +133,83 @@ struct Wg {
     static_assert(E * T == N && Q * T == E && N % NPL == 0, "geometry");
 };
 
+// A whole N x N tile of complex T must fit the CU's 160 KiB LDS for the exchanges of the 2-D tile kernels.  The one
+// geometry where it does not (N = 128 in fp64: 258 KiB) exchanges the real and the imaginary parts one after the
+// other through a buffer of N x (N+1) scalars (129 KiB): twice the barriers, same data path.
+template <int N, typename T>
+constexpr bool split_tile() { return sizeof(cx<T>) * (size_t)Wg<N>::LDS_ELEMS > 160u * 1024u; }
+template <int N, typename T>
+constexpr size_t tile_lds_bytes() { return (size_t)Wg<N>::LDS_ELEMS * (split_tile<N, T>() ? sizeof(T) : sizeof(cx<T>)); }
+template <int N, typename T>
+constexpr size_t line_lds_bytes() { return (size_t)Wg<N>::LINE_LDS_ELEMS * sizeof(cx<T>); }
+
 // ---- one distributed 1-D transform -------------------------------------------------------------------------
 // v[m] = x[u + T*m] on entry, X[u + T*m] on exit.  lds rows are indexed by position along the line, columns
 // by the lane index p.  tw[n] = exp(-2*pi*i*n/N) (forward table; conjugated for SGN = +1).
-// twr[k1-1] = tw[u*k1] are this thread's E-1 inter-step twiddles, loaded once per kernel by load_twiddles()
-// (wave-uniform for N >= 64, so they live in SGPRs and cost no vector-memory latency inside the direction loops).
-template <int N, typename T, class Ctx>
-BFSM_HD void load_twiddles(cx<T>* twr, const cx<T>* tw, int u, Ctx& ctx) {
+// Twiddles<N,T>: this thread's E-1 inter-step twiddles tw[u*k1].  Normally they are loaded once per kernel
+// (wave-uniform for N >= 64, so they live in SGPRs and cost no vector-memory latency inside the direction loops);
+// in the split-exchange geometry (N = 128, fp64: 60 SGPRs of twiddles next to 64 of phase factors would spill) only
+// the table position is kept and every use is a fresh scalar load from the constant cache.
+template <int N, typename T>
+struct Twiddles {
+    static constexpr bool HELD = !split_tile<N, T>();
+    cx<T> w[HELD ? Wg<N>::E - 1 : 1];
+    const cx<T>* row;   // tw + 0, indexed by u*k1
+    int u;
+    template <class Ctx>
+    BFSM_HD void load(const cx<T>* tw, int u_, Ctx& ctx) {
+        row = tw;
+        u = u_;
+        if constexpr (HELD) {
 #pragma unroll
-    for (int k1 = 1; k1 < Wg<N>::E; ++k1) twr[k1 - 1] = ctx.ldc(tw + u * k1);
-}
+            for (int k1 = 1; k1 < Wg<N>::E; ++k1) w[k1 - 1] = ctx.ldc(tw + u_ * k1);
+        }
+    }
+    template <class Ctx>
+    BFSM_HD cx<T> get(int k1, Ctx& ctx) const {
+        if constexpr (HELD) return w[k1 - 1];
+        else return ctx.ldc(row + ctx.opaque(u) * k1);   // opaque: keeps the load where it is used (no hoisting)
+    }
+};
 
-template <int N, int NP, int SGN, typename T, class Ctx>
-BFSM_HD void fft_line_np(cx<T>* v, cx<T>* lds, int p, int u, const cx<T>* twr, Ctx& ctx) {
+template <int N, int NP, int SGN, typename T, bool SPLIT = false, class Ctx>
+BFSM_HD void fft_line_np(cx<T>* v, cx<T>* lds, int p, int u, const Twiddles<N, T>& twr, Ctx& ctx) {
     constexpr int E = Wg<N>::E, TT = Wg<N>::T, Q = Wg<N>::Q, LS = NP + 1;   // p in [0, NP): LDS column
     SmallDft<E, SGN, T>::run(v);
 #pragma unroll
     for (int k1 = 1; k1 < E; ++k1) {
-        const cx<T> w = twr[k1 - 1];
+        const cx<T> w = twr.get(k1, ctx);
         v[k1] = (SGN < 0) ? cmul(v[k1], w) : cmulc(v[k1], w);
     }
-    ctx.sync();  // previous readers of lds are done
-#pragma unroll
-    for (int k1 = 0; k1 < E; ++k1) lds[(k1 * TT + u) * LS + p] = v[k1];
-    ctx.sync();
     cx<T> w2[E];
+    if constexpr (!SPLIT) {
+        ctx.sync();  // previous readers of lds are done
 #pragma unroll
-    for (int q = 0; q < Q; ++q)
+        for (int k1 = 0; k1 < E; ++k1) lds[(k1 * TT + u) * LS + p] = v[k1];
+        ctx.sync();
 #pragma unroll
-        for (int uu = 0; uu < TT; ++uu) w2[q * TT + uu] = lds[((u + TT * q) * TT + uu) * LS + p];
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+            for (int uu = 0; uu < TT; ++uu) w2[q * TT + uu] = lds[((u + TT * q) * TT + uu) * LS + p];
+    } else {   // real parts, then imaginary parts, through a scalar buffer (see split_tile)
+        T* ls = reinterpret_cast<T*>(lds);
+        ctx.sync();
+#pragma unroll
+        for (int k1 = 0; k1 < E; ++k1) ls[(k1 * TT + u) * LS + p] = v[k1].x;
+        ctx.sync();
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+            for (int uu = 0; uu < TT; ++uu) w2[q * TT + uu].x = ls[((u + TT * q) * TT + uu) * LS + p];
+        ctx.sync();
+#pragma unroll
+        for (int k1 = 0; k1 < E; ++k1) ls[(k1 * TT + u) * LS + p] = v[k1].y;
+        ctx.sync();
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+            for (int uu = 0; uu < TT; ++uu) w2[q * TT + uu].y = ls[((u + TT * q) * TT + uu) * LS + p];
+    }
 #pragma unroll
     for (int q = 0; q < Q; ++q) SmallDft<TT, SGN, T>::run(w2 + q * TT);
     // output index k1 + E*k2 with k1 = u + T*q  ==  u + T*(q + Q*k2)
@@ -172,23 +220,39 @@ BFSM_HD void fft_line_np(cx<T>* v, cx<T>* lds, int p, int u, const cx<T>* twr, C
 }
 
 template <int N, int SGN, typename T, class Ctx>
-BFSM_HD void fft_line(cx<T>* v, cx<T>* lds, int p, int u, const cx<T>* twr, Ctx& ctx) {
-    fft_line_np<N, N, SGN, T>(v, lds, p, u, twr, ctx);
+BFSM_HD void fft_line(cx<T>* v, cx<T>* lds, int p, int u, const Twiddles<N, T>& twr, Ctx& ctx) {
+    fft_line_np<N, N, SGN, T, split_tile<N, T>()>(v, lds, p, u, twr, ctx);
 }
 
 // ---- 2-D transform of an N x N tile with transposition -------------------------------------------------------
 // entry: v[m] = tile[a = u + T*m][c = p]      (c is the contiguous axis of the source)
 // exit : v[m] = TILE[a' = p][c' = u + T*m]    (to be stored as out[c'][a'], a' contiguous)
 template <int N, int SGN, typename T, class Ctx>
-BFSM_HD void fft_tile(cx<T>* v, cx<T>* lds, int p, int u, const cx<T>* twr, Ctx& ctx) {
+BFSM_HD void fft_tile(cx<T>* v, cx<T>* lds, int p, int u, const Twiddles<N, T>& twr, Ctx& ctx) {
     constexpr int E = Wg<N>::E, TT = Wg<N>::T, LS = Wg<N>::LS;
     fft_line<N, SGN, T>(v, lds, p, u, twr, ctx);  // along a
-    ctx.sync();
+    if constexpr (!split_tile<N, T>()) {
+        ctx.sync();
 #pragma unroll
-    for (int m = 0; m < E; ++m) lds[(u + TT * m) * LS + p] = v[m];  // row a', column c
-    ctx.sync();
+        for (int m = 0; m < E; ++m) lds[(u + TT * m) * LS + p] = v[m];  // row a', column c
+        ctx.sync();
 #pragma unroll
-    for (int m = 0; m < E; ++m) v[m] = lds[p * LS + (u + TT * m)];  // lane = a', own c = u + T*m
+        for (int m = 0; m < E; ++m) v[m] = lds[p * LS + (u + TT * m)];  // lane = a', own c = u + T*m
+    } else {
+        T* ls = reinterpret_cast<T*>(lds);
+        ctx.sync();
+#pragma unroll
+        for (int m = 0; m < E; ++m) ls[(u + TT * m) * LS + p] = v[m].x;
+        ctx.sync();
+#pragma unroll
+        for (int m = 0; m < E; ++m) v[m].x = ls[p * LS + (u + TT * m)];
+        ctx.sync();
+#pragma unroll
+        for (int m = 0; m < E; ++m) ls[(u + TT * m) * LS + p] = v[m].y;
+        ctx.sync();
+#pragma unroll
+        for (int m = 0; m < E; ++m) v[m].y = ls[p * LS + (u + TT * m)];
+    }
     fft_line<N, SGN, T>(v, lds, p, u, twr, ctx);  // along c
 }
 
@@ -348,8 +412,8 @@ BFSM_HD void body_tile_fwd_real(const TileFwdRealParams<T>& prm, Ctx& ctx) {
     const int x = ctx.bx();
     const size_t boff = (size_t)ctx.by() * N * N * N;      // batch member
     cx<T>* lds = ctx.template lds<cx<T>>();
-    cx<T> twr[E - 1];
-    load_twiddles<N, T>(twr, prm.tw, u, ctx);
+    Twiddles<N, T> twr;
+    twr.load(prm.tw, u, ctx);
     cx<T> v[E];
     const double* src = prm.f + boff + (size_t)x * N * N;
 #pragma unroll
@@ -368,8 +432,8 @@ BFSM_HD void body_tile_c2c(const LineParams<T>& prm, Ctx& ctx) {
     const int tid = ctx.tid(), p = tid % N, u = ctx.uniform(tid / N, N);
     const size_t base = ((size_t)ctx.by() * N + ctx.bx()) * N * N;
     cx<T>* lds = ctx.template lds<cx<T>>();
-    cx<T> twr[E - 1];
-    load_twiddles<N, T>(twr, prm.tw, u, ctx);
+    Twiddles<N, T> twr;
+    twr.load(prm.tw, u, ctx);
     cx<T> v[E];
 #pragma unroll
     for (int m = 0; m < E; ++m) v[m] = prm.in[base + (u + TT * m) * N + p];
@@ -387,8 +451,8 @@ BFSM_HD void body_line(const LineParams<T>& prm, Ctx& ctx) {
     const int tid = ctx.tid(), p = tid % NPL, u = ctx.uniform(tid / NPL, NPL);   // p: column inside this block of NPL
     const size_t base = (size_t)ctx.by() * N * N * N + (size_t)ctx.bx() * NPL + p;
     cx<T>* lds = ctx.template lds<cx<T>>();
-    cx<T> twr[E - 1];
-    load_twiddles<N, T>(twr, prm.tw, u, ctx);
+    Twiddles<N, T> twr;
+    twr.load(prm.tw, u, ctx);
     cx<T> v[E];
 #pragma unroll
     for (int m = 0; m < E; ++m) v[m] = prm.in[base + (size_t)(u + TT * m) * N * N];
@@ -406,13 +470,19 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
     const int tid = ctx.tid(), p = tid % N, u = ctx.uniform(tid / N, N);
     const int lxi = ctx.bx();
     cx<T>* lds = ctx.template lds<cx<T>>();
-    cx<T> twr[E - 1];
-    load_twiddles<N, T>(twr, prm.tw, u, ctx);
-    cx<T> fh[E];
+    Twiddles<N, T> twr;
+    twr.load(prm.tw, u, ctx);
+    // The workgroup's f_hat plane stays in registers across the direction loop, except in the one geometry whose
+    // 1024-thread workgroup leaves 128 VGPRs for 2 x 64 of data (N = 128, fp64): there it is re-read every
+    // iteration (a 256 KiB plane shared by the workgroups of the plane: L2 / Infinity Cache traffic).
+    constexpr bool KEEP = !split_tile<N, T>();
+    cx<T> fh[KEEP ? E : 1];
     const size_t bz = (size_t)ctx.bz();
     const cx<T>* src = prm.fhat + bz * N * N * N + (size_t)lxi * N * N;
+    if constexpr (KEEP) {
 #pragma unroll
-    for (int m = 0; m < E; ++m) fh[m] = src[(u + TT * m) * N + p];  // [lz = u + T m][ly = p]
+        for (int m = 0; m < E; ++m) fh[m] = src[(u + TT * m) * N + p];  // [lz = u + T m][ly = p]
+    }
     const int d_begin = ctx.by() * prm.per_group;
     int d_end = d_begin + prm.per_group;
     if (d_end > prm.n_dir) d_end = prm.n_dir;
@@ -433,7 +503,10 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
 #pragma unroll
         for (int m = 0; m < E; ++m) {
             const cx<T> ph = cmul(c0, ctx.ldc(prm.phz + b * N + u + TT * m));
-            v[m] = conj ? cmulc(fh[m], ph) : cmul(fh[m], ph);   // conj(alpha1) f_hat / G  :  alpha1 f_hat / G
+            cx<T> fm;
+            if constexpr (KEEP) fm = fh[m]; else fm = src[(u + TT * m) * N + p];
+            v[m] = conj ? cmulc(fm, ph) : cmul(fm, ph);   // conj(alpha1) f_hat / G  :  alpha1 f_hat / G
+            if constexpr (!KEEP) { if ((m & 3) == 3) ctx.sched_fence(); }   // at most 4 re-read points in flight
         }
         fft_tile<N, +1, T>(v, lds, p, u, twr, ctx);
         cx<T>* dst = (conj ? prm.a2 : prm.a1) + bz * prm.a_bstride + ((size_t)d * prm.planes + lxi) * N * N;
@@ -451,8 +524,8 @@ BFSM_HD void body_gain_line(const GainLineParams<T>& prm, Ctx& ctx) {
     const int tid = ctx.tid(), p = tid % NPL, u = ctx.uniform(tid / NPL, NPL);   // p: column inside this block of NPL
     const size_t base = (size_t)ctx.bz() * prm.a_bstride + (size_t)ctx.by() * N * N * N + (size_t)ctx.bx() * NPL + p;
     cx<T>* lds = ctx.template lds<cx<T>>();
-    cx<T> twr[E - 1];
-    load_twiddles<N, T>(twr, prm.tw, u, ctx);
+    Twiddles<N, T> twr;
+    twr.load(prm.tw, u, ctx);
     cx<T> a[E], b[E];
 #pragma unroll
     for (int m = 0; m < E; ++m) a[m] = ctx.ld_stream(prm.a1 + base + (size_t)(u + TT * m) * N * N);
@@ -477,8 +550,8 @@ BFSM_HD void body_gain_line_acc(const GainLineAccParams<T>& prm, Ctx& ctx) {
     constexpr int NPL = Wg<N>::NPL;
     const int tid = ctx.tid(), p = tid % NPL, u = ctx.uniform(tid / NPL, NPL);   // p: column inside this block of NPL
     cx<T>* lds = ctx.template lds<cx<T>>();
-    cx<T> twr[E - 1];
-    load_twiddles<N, T>(twr, prm.tw, u, ctx);
+    Twiddles<N, T> twr;
+    twr.load(prm.tw, u, ctx);
     const Segment seg = prm.segs[prm.seg0 + ctx.by()];
     const size_t row = (size_t)ctx.bx() * NPL + p;
     cx<T> acc[E];
@@ -515,8 +588,8 @@ BFSM_HD void body_nyq_rows(const NyqRowsParams<T>& prm, Ctx& ctx) {
     constexpr int E = Wg<N>::E, TT = Wg<N>::T, NPL = Wg<N>::NPL, NQ = N / 2 - 1, H = N / 2;
     const int tid = ctx.tid(), p = tid % NPL, u = ctx.uniform(tid / NPL, NPL);
     cx<T>* lds = ctx.template lds<cx<T>>();
-    cx<T> twr[E - 1];
-    load_twiddles<N, T>(twr, prm.tw, u, ctx);
+    Twiddles<N, T> twr;
+    twr.load(prm.tw, u, ctx);
     const int c = ctx.bx() * NPL + p;              // column
     const bool live = c < 2 * NQ;
     const int kind = live ? c / NQ : 0, j = live ? c % NQ : 0;
@@ -590,8 +663,8 @@ BFSM_HD void body_gain_line_acc_h(const GainLineAccHParams<T>& prm, Ctx& ctx) {
     constexpr int E = Wg<N>::E, TT = Wg<N>::T, NPL = Wg<N>::NPL, NQ = N / 2 - 1, NH = N / 2 + 1;
     const int tid = ctx.tid(), p = tid % NPL, u = ctx.uniform(tid / NPL, NPL);
     cx<T>* lds = ctx.template lds<cx<T>>();
-    cx<T> twr[E - 1];
-    load_twiddles<N, T>(twr, prm.tw, u, ctx);
+    Twiddles<N, T> twr;
+    twr.load(prm.tw, u, ctx);
     const Segment seg = prm.segs[prm.seg0 + ctx.by()];
     constexpr int BPR = N / NPL;                               // column blocks per row of N
     const int y = ctx.bx() / BPR, z = (ctx.bx() % BPR) * NPL + p;   // y is uniform over the workgroup
@@ -632,24 +705,41 @@ BFSM_HD void body_gain_fwd(const GainFwdParams<T>& prm, Ctx& ctx) {
     const int tid = ctx.tid(), p = tid % N, u = ctx.uniform(tid / N, N);
     const int x = ctx.bx();
     cx<T>* lds = ctx.template lds<cx<T>>();
-    cx<T> twr[E - 1];
-    load_twiddles<N, T>(twr, prm.tw, u, ctx);
+    Twiddles<N, T> twr;
+    twr.load(prm.tw, u, ctx);
     cx<T> acc[E];
 #pragma unroll
     for (int m = 0; m < E; ++m) acc[m] = {(T)0, (T)0};
     const Segment seg = prm.segs[prm.seg0 + ctx.by()];
-    for (int d = seg.d0; d < seg.d0 + seg.n; ++d) {
-        const cx<T>* src = prm.p + (size_t)ctx.bz() * prm.p_bstride + ((size_t)d * N + x) * N * N;
-        cx<T> v[E];
+    if constexpr (!split_tile<N, T>()) {
+        for (int d = seg.d0; d < seg.d0 + seg.n; ++d) {
+            const cx<T>* src = prm.p + (size_t)ctx.bz() * prm.p_bstride + ((size_t)d * N + x) * N * N;
+            cx<T> v[E];
 #pragma unroll
-        for (int m = 0; m < E; ++m) v[m] = ctx.ld_stream(src + (u + TT * m) * N + p);  // [y = u + T m][z = p]
-        fft_tile<N, -1, T>(v, lds, p, u, twr, ctx);
-        const T w = prm.dirw[prm.dir0 + d];
+            for (int m = 0; m < E; ++m) v[m] = ctx.ld_stream(src + (u + TT * m) * N + p);  // [y = u + T m][z = p]
+            fft_tile<N, -1, T>(v, lds, p, u, twr, ctx);
+            const T w = prm.dirw[prm.dir0 + d];
 #pragma unroll
-        for (int m = 0; m < E; ++m) {
-            acc[m].x += w * v[m].x;
-            acc[m].y += w * v[m].y;
+            for (int m = 0; m < E; ++m) {
+                acc[m].x += w * v[m].x;
+                acc[m].y += w * v[m].y;
+            }
         }
+    } else {
+        // N = 128 in fp64: accumulators plus a second tile of data exceed the 128 VGPRs of a 1024-thread workgroup.
+        // The transform is linear, so the weighted sum over the segment is formed on the inputs and transformed once
+        // (same bytes read; rounding order differs from the per-direction form at the 1e-16 level).
+        for (int d = seg.d0; d < seg.d0 + seg.n; ++d) {
+            const cx<T>* src = prm.p + (size_t)ctx.bz() * prm.p_bstride + ((size_t)d * N + x) * N * N;
+            const T w = prm.dirw[prm.dir0 + d];
+#pragma unroll
+            for (int m = 0; m < E; ++m) {
+                const cx<T> t = ctx.ld_stream(src + (u + TT * m) * N + p);
+                acc[m].x += w * t.x;
+                acc[m].y += w * t.y;
+            }
+        }
+        fft_tile<N, -1, T>(acc, lds, p, u, twr, ctx);
     }
     cx<T>* dst = prm.slab + (size_t)ctx.bz() * prm.slab_bstride + ((size_t)(prm.seg0 + ctx.by()) * N + x) * N * N;
 #pragma unroll
@@ -686,8 +776,8 @@ BFSM_HD void body_tail_inv(const TailInvParams<T>& prm, Ctx& ctx) {
     const int lxi = ctx.bx();
     const bool loss = ctx.by() != 0;
     cx<T>* lds = ctx.template lds<cx<T>>();
-    cx<T> twr[E - 1];
-    load_twiddles<N, T>(twr, prm.tw, u, ctx);
+    Twiddles<N, T> twr;
+    twr.load(prm.tw, u, ctx);
     cx<T> v[E];
     const size_t pbase = (size_t)ctx.bz() * N * N * N + (size_t)lxi * N * N;
     if (!loss) {
@@ -718,8 +808,8 @@ BFSM_HD void body_tail_line(const TailLineParams<T>& prm, Ctx& ctx) {
     const int tid = ctx.tid(), p = tid % NPL, u = ctx.uniform(tid / NPL, NPL);   // p: column inside this block of NPL
     const size_t base = (size_t)ctx.by() * N * N * N + (size_t)ctx.bx() * NPL + p;
     cx<T>* lds = ctx.template lds<cx<T>>();
-    cx<T> twr[E - 1];
-    load_twiddles<N, T>(twr, prm.tw, u, ctx);
+    Twiddles<N, T> twr;
+    twr.load(prm.tw, u, ctx);
     cx<T> g[E], l[E];
 #pragma unroll
     for (int m = 0; m < E; ++m) g[m] = prm.tg[base + (size_t)(u + TT * m) * N * N];

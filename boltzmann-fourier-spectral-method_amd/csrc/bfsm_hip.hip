@@ -25,6 +25,14 @@ struct DevCtx {
     __device__ __forceinline__ int by() const { return (int)blockIdx.y; }
     __device__ __forceinline__ int bz() const { return (int)blockIdx.z; }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
+    // nothing is scheduled across this point (bounds how many loads the compiler keeps in flight, i.e. registers)
+    __device__ __forceinline__ void sched_fence() const { __builtin_amdgcn_sched_barrier(0); }
+    // a wave-uniform value the optimiser may not reason about: loads addressed through it are neither hoisted out of
+    // loops nor merged, so they occupy SGPRs only where they are used
+    __device__ __forceinline__ int opaque(int v) const {
+        asm volatile("" : "+s"(v));
+        return v;
+    }
     // value known to be equal across a wave when a row of n lanes covers whole waves: make it an SGPR so the
     // twiddle / phase-table loads that depend on it become scalar loads
     __device__ __forceinline__ int uniform(int v, int n) const {
@@ -67,7 +75,7 @@ constexpr int kernel_threads() {
 }
 template <K kind, int N, typename T>
 constexpr size_t kernel_lds_bytes() {
-    return kind == K::Reduce ? 0 : (size_t)(is_line_kind(kind) ? Wg<N>::LINE_LDS_ELEMS : Wg<N>::LDS_ELEMS) * sizeof(cx<T>);
+    return kind == K::Reduce ? 0 : (is_line_kind(kind) ? line_lds_bytes<N, T>() : tile_lds_bytes<N, T>());
 }
 
 // Minimum waves per SIMD the register allocator must leave room for.  N=64: a 512-thread workgroup is 2 waves per
@@ -77,7 +85,7 @@ constexpr int kernel_min_waves() {
     if (kind == K::Reduce) return 1;
     if (N == 64) return sizeof(T) == 4 ? BFSM_F32_N64_WAVES : 4;   // fp32 tiles are 33 KiB: more workgroups fit
     if (N == 32) return 4;                                         // 128-thread workgroups: 8 per CU at <= 128 VGPRs
-    if (N == 128 && is_line_kind(kind)) return 4;
+    if (N == 128 && is_line_kind(kind)) return sizeof(T) == 4 ? 4 : 2;   // fp64: 133 KiB of columns, one workgroup per CU
     return 1;
 }
 
@@ -171,9 +179,7 @@ struct HipBackend {
             case 16: launch_n<kind, 16, T>(gx, gy, gz, prm); break;
             case 32: launch_n<kind, 32, T>(gx, gy, gz, prm); break;
             case 64: launch_n<kind, 64, T>(gx, gy, gz, prm); break;
-            case 128:
-                if constexpr (sizeof(T) == 4) launch_n<kind, 128, T>(gx, gy, gz, prm);
-                break;
+            case 128: launch_n<kind, 128, T>(gx, gy, gz, prm); break;
             default: break;
         }
     }

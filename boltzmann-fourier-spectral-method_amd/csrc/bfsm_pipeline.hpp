@@ -65,7 +65,6 @@ inline int validate_desc(const bfsm_desc& d, std::string& err) {
     const int N = d.nvx;
     if (N != 16 && N != 32 && N != 64 && N != 128) { err = "grid size must be one of 16, 32, 64, 128"; return BFSM_ERR_UNSUPPORTED; }
     if (d.precision != BFSM_F64 && d.precision != BFSM_F32) { err = "precision must be BFSM_F64 or BFSM_F32"; return BFSM_ERR_INVALID; }
-    if (N == 128 && d.precision == BFSM_F64) { err = "N=128 needs BFSM_F32 (a 128x128 double tile exceeds the 160 KiB LDS)"; return BFSM_ERR_UNSUPPORTED; }
     if (d.n_gl < 1 || d.n_sph < 1) { err = "n_gl and n_sph must be positive"; return BFSM_ERR_INVALID; }
     if (!d.gl_nodes || !d.gl_wts || !d.sph_wts || !d.sx || !d.sy || !d.sz) { err = "null quadrature array"; return BFSM_ERR_INVALID; }
     if (!(d.L > 0)) { err = "L must be positive"; return BFSM_ERR_INVALID; }

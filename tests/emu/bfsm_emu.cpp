@@ -34,6 +34,8 @@ struct EmuCtx {
     template <class U> U ld_stream(const U* p) const { return *p; }
     template <class U> void st_stream(U* p, U v) const { *p = v; }
     void sync();       // workgroup barrier
+    void sched_fence() const {}   // compiler scheduling hint on the device; nothing to do on the host
+    int opaque(int v) const { return v; }
     void wave_sync();  // ordering point inside one wave of 64 threads
 };
 
@@ -154,8 +156,7 @@ struct EmuBackend {
     void launch_n(int gx, int gy, int gz, const P& prm) {
         const int threads = kind == bfsm::K::Reduce ? 256
                             : (bfsm::is_line_kind(kind) ? bfsm::Wg<N>::LINE_THREADS : bfsm::Wg<N>::THREADS);
-        smem.assign((size_t)(bfsm::is_line_kind(kind) ? bfsm::Wg<N>::LINE_LDS_ELEMS : bfsm::Wg<N>::LDS_ELEMS) *
-                        sizeof(bfsm::cx<T>), 0xCD);
+        smem.assign(bfsm::is_line_kind(kind) ? bfsm::line_lds_bytes<N, T>() : bfsm::tile_lds_bytes<N, T>(), 0xCD);
         P copy = prm;
         for (int bz = 0; bz < gz; ++bz)
             for (int by = 0; by < gy; ++by)
@@ -171,9 +172,7 @@ struct EmuBackend {
             case 16: launch_n<kind, 16, T>(gx, gy, gz, prm); break;
             case 32: launch_n<kind, 32, T>(gx, gy, gz, prm); break;
             case 64: launch_n<kind, 64, T>(gx, gy, gz, prm); break;
-            case 128:
-                if constexpr (sizeof(T) == 4) launch_n<kind, 128, T>(gx, gy, gz, prm);
-                break;
+            case 128: launch_n<kind, 128, T>(gx, gy, gz, prm); break;
             default: break;
         }
     }
@@ -267,7 +266,7 @@ int bfsm_emu_finish(const bfsm_desc* d, const double* f, const double* qhat_in, 
 // Emulated bfsm_fft3d; data = batch*G interleaved complex doubles (narrowed to float when precision == 32).
 int bfsm_emu_fft3d(int N, int precision, double* data, int batch, int sign) {
     if (N != 16 && N != 32 && N != 64 && N != 128) return BFSM_ERR_UNSUPPORTED;
-    if (precision == BFSM_F64) { if (N == 128) return BFSM_ERR_UNSUPPORTED; return emu::fft3d_t<double>(N, data, batch, sign); }
+    if (precision == BFSM_F64) return emu::fft3d_t<double>(N, data, batch, sign);
     return emu::fft3d_t<float>(N, data, batch, sign);
 }
 

@@ -52,8 +52,8 @@ def test_descriptor_validation_errors_are_reported(libpath):
     bad_n = capi.Desc(48, 48, 48, 4, 4, p, p, p, p, p, p, 0.0, 1.0, 1.0, 64, 0, 0, 0, 0, 0)
     assert L.bfsm_create(ctypes.byref(bad_n), ctypes.byref(h)) == 2
     assert b"16, 32, 64, 128" in L.bfsm_last_error(None)
-    bad_prec = capi.Desc(128, 128, 128, 4, 4, p, p, p, p, p, p, 0.0, 1.0, 1.0, 64, 0, 0, 0, 0, 0)
-    assert L.bfsm_create(ctypes.byref(bad_prec), ctypes.byref(h)) == 2
+    bad_prec = capi.Desc(128, 128, 128, 4, 4, p, p, p, p, p, p, 0.0, 1.0, 1.0, 16, 0, 0, 0, 0, 0)
+    assert L.bfsm_create(ctypes.byref(bad_prec), ctypes.byref(h)) == 1
     bad_shard = capi.Desc(16, 16, 16, 4, 4, p, p, p, p, p, p, 0.0, 1.0, 1.0, 64, 0, 3, 99, 0, 0)
     assert L.bfsm_create(ctypes.byref(bad_shard), ctypes.byref(h)) == 1
     assert L.bfsm_create(None, ctypes.byref(h)) == 1

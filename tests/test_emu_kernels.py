@@ -14,7 +14,7 @@ GAMMA, B_GAMMA, R = 0.0, 1.0 / (4.0 * np.pi), 10.0
 
 
 @pytest.mark.parametrize("n,prec,tol", [(16, 64, 2e-15), (32, 64, 2e-15), (64, 64, 3e-15), (16, 32, 1e-6),
-                                        (32, 32, 1e-6), (64, 32, 1e-6), (128, 32, 1e-6)])
+                                        (32, 32, 1e-6), (64, 32, 1e-6), (128, 32, 1e-6), (128, 64, 3e-15)])
 def test_fft3d_matches_numpy_and_round_trips(n, prec, tol):
     """Mirrors the reference's FFT check (fftw_benchmark.cpp:137-171): forward, scale 1/G, inverse."""
     rng = np.random.default_rng(n + prec)
@@ -46,6 +46,20 @@ def test_collide_n64_matches_oracle(oracle):
     f, _, L, _ = oracle.bkw(64)
     f = oracle.perturbed_input(f)
     gl = oracle.gauss_legendre(2, 0.0, R)
+    sph = oracle.spherical_design(6)
+    Q, qhat = E.collide(f, gl, sph, GAMMA, B_GAMMA, L, 64, max_chunk=4)
+    Qo, qo = oracle.collide(f, gl, sph, GAMMA, B_GAMMA, L, return_qhat=True)
+    assert np.abs(qhat - qo).max() <= 1e-12 * np.abs(qo).max()
+    assert np.abs(Q - Qo).max() <= 1e-12 * np.abs(Qo).max()
+
+
+@pytest.mark.slow
+def test_collide_n128_fp64_matches_oracle(oracle):
+    """The split-exchange geometry (N = 128 in fp64: real and imaginary parts exchanged one after the other, f_hat
+    re-read per direction, segment sum formed before the (y,z) forward transform)."""
+    f, _, L, _ = oracle.bkw(128)
+    f = oracle.perturbed_input(f)
+    gl = oracle.gauss_legendre(1, 0.0, R)
     sph = oracle.spherical_design(6)
     Q, qhat = E.collide(f, gl, sph, GAMMA, B_GAMMA, L, 64, max_chunk=4)
     Qo, qo = oracle.collide(f, gl, sph, GAMMA, B_GAMMA, L, return_qhat=True)
@@ -109,8 +123,9 @@ def test_plan_chunks_and_segments_cover_shard_once():
 def test_plan_rejects_unsupported():
     with pytest.raises(ValueError):
         E.plan(48, 2, 6)
+    E.plan(128, 2, 6, 64)                # N=128 in fp64 is planned like any other size (split-exchange tiles)
     with pytest.raises(ValueError):
-        E.plan(128, 2, 6, 64)            # N=128 needs fp32
+        E.plan(16, 2, 6, 16)             # precision must be 32 or 64
     with pytest.raises(ValueError):
         E.plan(16, 2, 6, 64, (5, 40))    # shard beyond n_gl*n_sph
 

@@ -65,7 +65,7 @@ def test_library_is_the_hip_one(torch_cuda):
 
 
 @pytest.mark.parametrize("n,prec,tol", [(16, 64, 3e-15), (32, 64, 3e-15), (64, 64, 4e-15), (16, 32, 1e-6),
-                                        (32, 32, 1e-6), (64, 32, 1e-6), (128, 32, 1e-6)])
+                                        (32, 32, 1e-6), (64, 32, 1e-6), (128, 32, 1e-6), (128, 64, 3e-15)])
 def test_fft3d_kernels(torch_cuda, n, prec, tol):
     """Hand-written Stockham passes vs numpy.fft + round trip (reference check: cufft_benchmark.cu:166-207)."""
     import bfsm
@@ -386,6 +386,29 @@ def test_n128_fp32_matches_oracle(torch_cuda, oracle):
         got = _collide(torch_cuda, op, f_h)
         op.destroy()
         assert np.abs(got - ref).max() <= TOL32 * np.abs(ref).max()
+
+
+def test_n128_fp64_matches_oracle(torch_cuda, oracle):
+    """N = 128 in double precision (the split-exchange geometry): faithful, exact-reduction and Hermitian paths against
+    the oracle at the fp64 tolerance, and a two-member batch."""
+    import bfsm
+    torch = torch_cuda
+    nv, n_gl, n_sph = 128, 2, 12
+    f_h = bfsm.perturbed_input(bfsm.bkw_solution(nv)[0])
+    ref = _oracle(oracle, f_h, n_gl, n_sph)
+    for exact, herm in ((False, False), (True, False), (True, True)):
+        op = _make(bfsm, nv, n_gl, n_sph, 64, exact=exact, hermitian=herm, max_chunk=7)
+        got = _collide(torch, op, f_h)
+        op.destroy()
+        assert np.abs(got - ref).max() <= TOL64 * np.abs(ref).max(), (exact, herm)
+    op = _make(bfsm, nv, n_gl, n_sph, 64, max_batch=2)
+    fb = torch.from_numpy(np.stack([f_h, 0.5 * f_h])).cuda()
+    Qb = torch.empty_like(fb)
+    op.computeCollisionBatch(Qb, fb, 2)
+    torch.cuda.synchronize()
+    op.destroy()
+    assert np.abs(Qb[0].cpu().numpy() - ref).max() <= TOL64 * np.abs(ref).max()
+    assert np.abs(Qb[1].cpu().numpy() - 0.25 * ref).max() <= TOL64 * np.abs(ref).max()
 
 
 def test_cpp_multi_gpu_driver_on_one_device(torch_cuda):
