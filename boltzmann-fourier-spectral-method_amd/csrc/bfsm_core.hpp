@@ -511,7 +511,8 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
         fft_tile<N, +1, T>(v, lds, p, u, twr, ctx);
         cx<T>* dst = (conj ? prm.a2 : prm.a1) + bz * prm.a_bstride + ((size_t)d * prm.planes + lxi) * N * N;
 #pragma unroll
-        for (int m = 0; m < E; ++m) ctx.st_stream(dst + (size_t)(u + TT * m) * N + p, v[m]);  // [y = u + T m][z = p]
+        for (int m = 0; m < E; ++m)   // [y = u + T m][z = p]
+            ctx.template st_stream_at<N % 64 == 0>(dst + (size_t)(u + TT * m) * N, (unsigned)p * (unsigned)sizeof(cx<T>), v[m]);
     }
 }
 
@@ -522,22 +523,28 @@ BFSM_HD void body_gain_line(const GainLineParams<T>& prm, Ctx& ctx) {
     constexpr int E = Wg<N>::E, TT = Wg<N>::T;
     constexpr int NPL = Wg<N>::NPL;
     const int tid = ctx.tid(), p = tid % NPL, u = ctx.uniform(tid / NPL, NPL);   // p: column inside this block of NPL
-    const size_t base = (size_t)ctx.bz() * prm.a_bstride + (size_t)ctx.by() * N * N * N + (size_t)ctx.bx() * NPL + p;
+    // wave-uniform row pointers + a 32-bit lane offset: the accesses take the scalar-base addressing form, so no
+    // per-access 64-bit address lives in VGPRs
+    const size_t ubase = (size_t)ctx.bz() * prm.a_bstride + (size_t)ctx.by() * N * N * N + (size_t)ctx.bx() * NPL;
+    cx<T>* A1 = prm.a1 + ubase;
+    const cx<T>* A2 = prm.a2 + ubase;
+    const unsigned pl = (unsigned)p * (unsigned)sizeof(cx<T>);   // lane offset in bytes
+    constexpr bool UNI = NPL % 64 == 0;
     cx<T>* lds = ctx.template lds<cx<T>>();
     Twiddles<N, T> twr;
     twr.load(prm.tw, u, ctx);
     cx<T> a[E], b[E];
 #pragma unroll
-    for (int m = 0; m < E; ++m) a[m] = ctx.ld_stream(prm.a1 + base + (size_t)(u + TT * m) * N * N);
+    for (int m = 0; m < E; ++m) a[m] = ctx.template ld_stream_at<UNI>(A1 + (size_t)(u + TT * m) * N * N, pl);
 #pragma unroll
-    for (int m = 0; m < E; ++m) b[m] = ctx.ld_stream(prm.a2 + base + (size_t)(u + TT * m) * N * N);
+    for (int m = 0; m < E; ++m) b[m] = ctx.template ld_stream_at<UNI>(A2 + (size_t)(u + TT * m) * N * N, pl);
     fft_line_np<N, NPL, +1, T>(a, lds, p, u, twr, ctx);
     fft_line_np<N, NPL, +1, T>(b, lds, p, u, twr, ctx);
 #pragma unroll
     for (int m = 0; m < E; ++m) a[m] = cmul(a[m], b[m]);
     fft_line_np<N, NPL, -1, T>(a, lds, p, u, twr, ctx);
 #pragma unroll
-    for (int m = 0; m < E; ++m) ctx.st_stream(prm.a1 + base + (size_t)(u + TT * m) * N * N, a[m]);
+    for (int m = 0; m < E; ++m) ctx.template st_stream_at<UNI>(A1 + (size_t)(u + TT * m) * N * N, pl, a[m]);
 }
 
 // KB' (exact-reduction mode).  grid = (N rows y, segments).  FFT linearity: beta1 depends on r only and the forward
@@ -716,7 +723,8 @@ BFSM_HD void body_gain_fwd(const GainFwdParams<T>& prm, Ctx& ctx) {
             const cx<T>* src = prm.p + (size_t)ctx.bz() * prm.p_bstride + ((size_t)d * N + x) * N * N;
             cx<T> v[E];
 #pragma unroll
-            for (int m = 0; m < E; ++m) v[m] = ctx.ld_stream(src + (u + TT * m) * N + p);  // [y = u + T m][z = p]
+            for (int m = 0; m < E; ++m)   // [y = u + T m][z = p]
+                v[m] = ctx.template ld_stream_at<N % 64 == 0>(src + (u + TT * m) * N, (unsigned)p * (unsigned)sizeof(cx<T>));
             fft_tile<N, -1, T>(v, lds, p, u, twr, ctx);
             const T w = prm.dirw[prm.dir0 + d];
 #pragma unroll
@@ -734,7 +742,7 @@ BFSM_HD void body_gain_fwd(const GainFwdParams<T>& prm, Ctx& ctx) {
             const T w = prm.dirw[prm.dir0 + d];
 #pragma unroll
             for (int m = 0; m < E; ++m) {
-                const cx<T> t = ctx.ld_stream(src + (u + TT * m) * N + p);
+                const cx<T> t = ctx.template ld_stream_at<N % 64 == 0>(src + (u + TT * m) * N, (unsigned)p * (unsigned)sizeof(cx<T>));
                 acc[m].x += w * t.x;
                 acc[m].y += w * t.y;
             }

@@ -33,9 +33,16 @@ struct EmuCtx {
     template <class U> U ldc(const U* p) const { return *p; }
     template <class U> U ld_stream(const U* p) const { return *p; }
     template <class U> void st_stream(U* p, U v) const { *p = v; }
+    template <bool UNI, class U> U ld_stream_at(const U* row, unsigned byte_off) const {
+        return *reinterpret_cast<const U*>(reinterpret_cast<const unsigned char*>(row) + byte_off);
+    }
+    template <bool UNI, class U> void st_stream_at(U* row, unsigned byte_off, U v) const {
+        *reinterpret_cast<U*>(reinterpret_cast<unsigned char*>(row) + byte_off) = v;
+    }
     void sync();       // workgroup barrier
     void sched_fence() const {}   // compiler scheduling hint on the device; nothing to do on the host
     int opaque(int v) const { return v; }
+    template <class U> U* uniform_ptr(U* p) const { return p; }
     void wave_sync();  // ordering point inside one wave of 64 threads
 };
 
