@@ -560,7 +560,9 @@ BFSM_HD void body_gain_line_acc(const GainLineAccParams<T>& prm, Ctx& ctx) {
     Twiddles<N, T> twr;
     twr.load(prm.tw, u, ctx);
     const Segment seg = prm.segs[prm.seg0 + ctx.by()];
-    const size_t row = (size_t)ctx.bx() * NPL + p;
+    const size_t row = (size_t)ctx.bx() * NPL;                   // uniform; the lane adds pl bytes
+    const unsigned pl = (unsigned)p * (unsigned)sizeof(cx<T>);
+    constexpr bool UNI = NPL % 64 == 0;
     cx<T> acc[E];
 #pragma unroll
     for (int m = 0; m < E; ++m) acc[m] = {(T)0, (T)0};
@@ -568,9 +570,9 @@ BFSM_HD void body_gain_line_acc(const GainLineAccParams<T>& prm, Ctx& ctx) {
         const size_t base = (size_t)ctx.bz() * prm.a_bstride + (size_t)d * N * N * N + row;
         cx<T> a[E], b[E];
 #pragma unroll
-        for (int m = 0; m < E; ++m) a[m] = ctx.ld_stream(prm.a1 + base + (size_t)(u + TT * m) * N * N);
+        for (int m = 0; m < E; ++m) a[m] = ctx.template ld_stream_at<UNI>(prm.a1 + base + (size_t)(u + TT * m) * N * N, pl);
 #pragma unroll
-        for (int m = 0; m < E; ++m) b[m] = ctx.ld_stream(prm.a2 + base + (size_t)(u + TT * m) * N * N);
+        for (int m = 0; m < E; ++m) b[m] = ctx.template ld_stream_at<UNI>(prm.a2 + base + (size_t)(u + TT * m) * N * N, pl);
         fft_line_np<N, NPL, +1, T>(a, lds, p, u, twr, ctx);
         fft_line_np<N, NPL, +1, T>(b, lds, p, u, twr, ctx);
         const T w = prm.dirw[prm.dir0 + d];
@@ -584,7 +586,7 @@ BFSM_HD void body_gain_line_acc(const GainLineAccParams<T>& prm, Ctx& ctx) {
     fft_line_np<N, NPL, -1, T>(acc, lds, p, u, twr, ctx);
     const size_t obase = (size_t)ctx.bz() * prm.pseg_bstride + (size_t)(prm.seg0 + ctx.by()) * N * N * N + row;
 #pragma unroll
-    for (int m = 0; m < E; ++m) prm.pseg[obase + (size_t)(u + TT * m) * N * N] = acc[m];
+    for (int m = 0; m < E; ++m) ctx.template st_at<UNI>(prm.pseg + obase + (size_t)(u + TT * m) * N * N, pl, acc[m]);
 }
 
 // KN (Hermitian mode).  grid = (column blocks, 2 * directions of the chunk, batch).  One column = one (kind, j):
@@ -637,21 +639,24 @@ BFSM_HD void body_nyq_rows(const NyqRowsParams<T>& prm, Ctx& ctx) {
 // loads of both arrays issue back to back: (1) raw loads -- m < E/2 are stored planes, m > E/2 mirrored planes,
 // m == E/2 (idx = N/2 + u) the stored Nyquist plane for u == 0 and a mirrored plane otherwise; (2) conjugation of
 // the mirrored rows plus the exact Nyquist terms (-1)^y R1[idx](z) + (-1)^z R2[idx](y).
+// colrow = first column of this workgroup's block (uniform), pl = lane offset in bytes.
 template <int N, typename T, class Ctx>
-BFSM_HD void hermitian_line_load(cx<T>* v, const cx<T>* A, int col, int u, Ctx& ctx) {
+BFSM_HD void hermitian_line_load(cx<T>* v, const cx<T>* A, int colrow, unsigned pl, int u, Ctx& ctx) {
     constexpr int E = Wg<N>::E, TT = Wg<N>::T, MS = E / 2;
     static_assert(TT * MS == N / 2, "split row");
 #pragma unroll
     for (int m = 0; m < E; ++m) {
         const int idx = u + TT * m;
         const int plane = (m < MS) ? idx : ((m > MS || u != 0) ? N - idx : idx);
-        v[m] = A[(size_t)plane * N * N + col];     // each stored row is read twice per iteration: keep it cacheable
+        // each stored row is read twice per iteration: keep it cacheable
+        v[m] = ctx.template ld_at<Wg<N>::NPL % 64 == 0>(A + (size_t)plane * N * N + colrow, pl);
     }
 }
 
 template <int N, typename T, class Ctx>
-BFSM_HD void hermitian_line_fix(cx<T>* v, const cx<T>* R, int y, int z, int u, Ctx& ctx) {
+BFSM_HD void hermitian_line_fix(cx<T>* v, const cx<T>* R, int y, int z0, int p, int u, Ctx& ctx) {
     constexpr int E = Wg<N>::E, TT = Wg<N>::T, NQ = N / 2 - 1, H = N / 2, MS = E / 2;
+    const int z = z0 + p;                                   // z0: first z of the block (uniform)
     const T sy = (y & 1) ? (T)-1 : (T)1, sz = (z & 1) ? (T)-1 : (T)1;
 #pragma unroll
     for (int m = MS; m < E; ++m) {
@@ -674,8 +679,9 @@ BFSM_HD void body_gain_line_acc_h(const GainLineAccHParams<T>& prm, Ctx& ctx) {
     twr.load(prm.tw, u, ctx);
     const Segment seg = prm.segs[prm.seg0 + ctx.by()];
     constexpr int BPR = N / NPL;                               // column blocks per row of N
-    const int y = ctx.bx() / BPR, z = (ctx.bx() % BPR) * NPL + p;   // y is uniform over the workgroup
-    const int col = y * N + z;
+    const int y = ctx.bx() / BPR, z0 = (ctx.bx() % BPR) * NPL;   // y, z0 are uniform over the workgroup; z = z0 + p
+    const int colrow = y * N + z0;
+    const unsigned pl = (unsigned)p * (unsigned)sizeof(cx<T>);
     cx<T> acc[E];
 #pragma unroll
     for (int m = 0; m < E; ++m) acc[m] = {(T)0, (T)0};
@@ -683,11 +689,11 @@ BFSM_HD void body_gain_line_acc_h(const GainLineAccHParams<T>& prm, Ctx& ctx) {
         const size_t abase = (size_t)ctx.bz() * prm.a_bstride + (size_t)d * NH * N * N;
         const cx<T>* R = prm.r + (size_t)ctx.bz() * prm.r_bstride + (size_t)d * 4 * NQ * N;
         cx<T> a[E], b[E];
-        hermitian_line_load<N, T>(a, prm.a1 + abase, col, u, ctx);
-        hermitian_line_fix<N, T>(a, R, y, z, u, ctx);
-        hermitian_line_load<N, T>(b, prm.a2 + abase, col, u, ctx);     // in flight while a is transformed
+        hermitian_line_load<N, T>(a, prm.a1 + abase, colrow, pl, u, ctx);
+        hermitian_line_fix<N, T>(a, R, y, z0, p, u, ctx);
+        hermitian_line_load<N, T>(b, prm.a2 + abase, colrow, pl, u, ctx);     // in flight while a is transformed
         fft_line_np<N, NPL, +1, T>(a, lds, p, u, twr, ctx);
-        hermitian_line_fix<N, T>(b, R + (size_t)2 * NQ * N, y, z, u, ctx);
+        hermitian_line_fix<N, T>(b, R + (size_t)2 * NQ * N, y, z0, p, u, ctx);
         fft_line_np<N, NPL, +1, T>(b, lds, p, u, twr, ctx);
         const T w = prm.dirw[prm.dir0 + d];
 #pragma unroll
@@ -698,9 +704,10 @@ BFSM_HD void body_gain_line_acc_h(const GainLineAccHParams<T>& prm, Ctx& ctx) {
         }
     }
     fft_line_np<N, NPL, -1, T>(acc, lds, p, u, twr, ctx);
-    const size_t obase = (size_t)ctx.bz() * prm.pseg_bstride + (size_t)(prm.seg0 + ctx.by()) * N * N * N + col;
+    const size_t obase = (size_t)ctx.bz() * prm.pseg_bstride + (size_t)(prm.seg0 + ctx.by()) * N * N * N + colrow;
 #pragma unroll
-    for (int m = 0; m < E; ++m) prm.pseg[obase + (size_t)(u + TT * m) * N * N] = acc[m];
+    for (int m = 0; m < E; ++m)
+        ctx.template st_at<NPL % 64 == 0>(prm.pseg + obase + (size_t)(u + TT * m) * N * N, pl, acc[m]);
 }
 
 // KC.  grid = (N planes x, segments of the chunk).  (y,z) part of the forward transform + the direction sum of

@@ -90,6 +90,37 @@ struct DevCtx {
         __builtin_nontemporal_store(r, (gvec)(g + byte_off));
 #pragma clang diagnostic pop
     }
+    // cacheable (plain) variants of the row + lane-offset accessors
+    template <bool UNI, class T>
+    __device__ __forceinline__ cx<T> ld_at(const cx<T>* row, unsigned byte_off) const {
+        if constexpr (!UNI) return *reinterpret_cast<const cx<T>*>(reinterpret_cast<const unsigned char*>(row) + byte_off);
+        typedef T vec2 __attribute__((ext_vector_type(2)));
+        typedef const unsigned char __attribute__((address_space(1))) * gptr;
+        typedef const vec2 __attribute__((address_space(1))) * gvec;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+        gptr g = (gptr)(reinterpret_cast<const unsigned char*>(row));
+        asm volatile("" : "+s"(g));
+        const vec2 r = *(gvec)(g + byte_off);
+#pragma clang diagnostic pop
+        return cx<T>{r.x, r.y};
+    }
+    template <bool UNI, class T>
+    __device__ __forceinline__ void st_at(cx<T>* row, unsigned byte_off, cx<T> v) const {
+        if constexpr (!UNI) { *reinterpret_cast<cx<T>*>(reinterpret_cast<unsigned char*>(row) + byte_off) = v; return; }
+        typedef T vec2 __attribute__((ext_vector_type(2)));
+        typedef unsigned char __attribute__((address_space(1))) * gptr;
+        typedef vec2 __attribute__((address_space(1))) * gvec;
+        vec2 r;
+        r.x = v.x;
+        r.y = v.y;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+        gptr g = (gptr)(reinterpret_cast<unsigned char*>(row));
+        asm volatile("" : "+s"(g));
+        *(gvec)(g + byte_off) = r;
+#pragma clang diagnostic pop
+    }
     // read-only table element through the constant address space: with a wave-uniform address the compiler
     // emits s_load (scalar data cache, SGPR result) even when the kernel also stores to global memory
     template <class T>

@@ -36,6 +36,8 @@ struct EmuCtx {
     template <bool UNI, class U> U ld_stream_at(const U* row, unsigned byte_off) const {
         return *reinterpret_cast<const U*>(reinterpret_cast<const unsigned char*>(row) + byte_off);
     }
+    template <bool UNI, class U> U ld_at(const U* row, unsigned byte_off) const { return ld_stream_at<UNI>(row, byte_off); }
+    template <bool UNI, class U> void st_at(U* row, unsigned byte_off, U v) const { st_stream_at<UNI>(row, byte_off, v); }
     template <bool UNI, class U> void st_stream_at(U* row, unsigned byte_off, U v) const {
         *reinterpret_cast<U*>(reinterpret_cast<unsigned char*>(row) + byte_off) = v;
     }
