@@ -212,6 +212,13 @@ def main():
         op.computeCollisionAsync(Q, f, torch.cuda.current_stream().cuda_stream) if world == 1 else \
             op.gainPartial(f, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
+    if world > 1:
+        # also set-up: RCCL builds its communicator / channels on the first collective of each kind; do that here so
+        # that a --warmup 0 run does not time it
+        for _ in range(2):
+            dist.all_reduce(Q2)
+            dist.all_reduce(Q2, async_op=True).wait()
+        fence()
     elapsed = timed(op)
 
     ms_per_step = 1e3 * elapsed / args.steps
