@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <exception>
 #include <mutex>
 #include <new>
 #include <string>
@@ -224,7 +225,7 @@ struct HipBackend {
             static std::atomic<unsigned long long> done{0};
             const unsigned long long bit = 1ull << (device & 63);
             if (!(done.load(std::memory_order_relaxed) & bit)) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                BFSM_NOTE(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 done.fetch_or(bit, std::memory_order_relaxed);
             }
         }
@@ -276,6 +277,28 @@ static int fail(bfsm_plan* h, int code, const std::string& msg) {
     return code;
 }
 
+// Makes the handle's device current for the duration of a call and puts the caller's device back afterwards: the
+// library never changes the calling thread's current device as a side effect.
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) err = hipSetDevice(dev); else prev = -1;   // nothing to restore when it already is current
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
+// No C++ exception may cross the C boundary (bfsm.h: "functions never throw"): host-side allocation failures of the
+// plan / table builders and anything unexpected become status codes.
+#define BFSM_GUARDED(h, body)                                                                         \
+    try { body }                                                                                      \
+    catch (const std::bad_alloc&) { return fail((h), BFSM_ERR_NOMEM, "out of host memory"); }         \
+    catch (const std::exception& ex) { return fail((h), BFSM_ERR_INVALID, std::string("internal error: ") + ex.what()); } \
+    catch (...) { return fail((h), BFSM_ERR_INVALID, "internal error (unknown exception)"); }
+
 static int check_hip(bfsm_plan* h, const char* where) {
     if (h->be.first_error == hipSuccess) return BFSM_OK;
     std::string m = std::string("HIP error: ") + hipGetErrorString(h->be.first_error) + " in " + h->be.first_error_where +
@@ -291,9 +314,7 @@ int bfsm_version(void) { return BFSM_VERSION; }
 
 const char* bfsm_last_error(bfsm_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
-int bfsm_create(const bfsm_desc* desc, bfsm_handle* out) {
-    if (!desc || !out) return fail(nullptr, BFSM_ERR_INVALID, "null argument");
-    *out = nullptr;
+static int create_impl(const bfsm_desc* desc, bfsm_handle* out, bfsm_plan*& h) {
     std::string err;
     int rc = bfsm::validate_desc(*desc, err);
     if (rc != BFSM_OK) return fail(nullptr, rc, err);
@@ -302,10 +323,9 @@ int bfsm_create(const bfsm_desc* desc, bfsm_handle* out) {
     if (e != hipSuccess || ndev <= 0)
         return fail(nullptr, BFSM_ERR_HIP, std::string("no HIP device available: ") + hipGetErrorString(e));
     if (desc->device < 0 || desc->device >= ndev) return fail(nullptr, BFSM_ERR_INVALID, "device ordinal out of range");
-    e = hipSetDevice(desc->device);
-    if (e != hipSuccess) return fail(nullptr, BFSM_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
-    bfsm_plan* h = new (std::nothrow) bfsm_plan();
-    if (!h) return fail(nullptr, BFSM_ERR_NOMEM, "out of host memory");
+    DeviceGuard guard(desc->device);
+    if (guard.err != hipSuccess) return fail(nullptr, BFSM_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(guard.err));
+    h = new bfsm_plan();
     h->desc = *desc;
     h->be.profile = (desc->flags & BFSM_FLAG_PROFILE) != 0;
     h->be.device = desc->device;
@@ -325,58 +345,95 @@ int bfsm_create(const bfsm_desc* desc, bfsm_handle* out) {
     else if (h->be.first_error != hipSuccess) { (void)check_hip(h, "bfsm_create"); err = h->err; }
     if (rc != BFSM_OK) {
         g_create_error = h->err.empty() ? err : h->err;
-        bfsm_destroy(h);
         return rc;
     }
     *out = h;
+    h = nullptr;   // ownership passed to the caller
     return BFSM_OK;
 }
 
-static int enter(bfsm_plan* h, void* stream) {
-    if (!h) return BFSM_ERR_INVALID;
-    hipError_t e = hipSetDevice(h->desc.device);
-    if (e != hipSuccess) return fail(h, BFSM_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+int bfsm_create(const bfsm_desc* desc, bfsm_handle* out) {
+    if (!desc || !out) return fail(nullptr, BFSM_ERR_INVALID, "null argument");
+    *out = nullptr;
+    bfsm_plan* h = nullptr;   // whatever create_impl leaves here (error or exception) is torn down
+    int rc;
+    try {
+        rc = create_impl(desc, out, h);
+    } catch (const std::bad_alloc&) {
+        rc = fail(nullptr, BFSM_ERR_NOMEM, "out of host memory");
+    } catch (const std::exception& ex) {
+        rc = fail(nullptr, BFSM_ERR_INVALID, std::string("internal error: ") + ex.what());
+    } catch (...) {
+        rc = fail(nullptr, BFSM_ERR_INVALID, "internal error (unknown exception)");
+    }
+    if (h) {
+        const std::string keep = g_create_error;   // bfsm_destroy must not disturb the message
+        bfsm_destroy(h);
+        g_create_error = keep;
+    }
+    return rc;
+}
+
+// Common prologue of the entry points (after the DeviceGuard): remember the stream of this call.
+static int enter(bfsm_plan* h, const DeviceGuard& g, void* stream) {
+    if (g.err != hipSuccess) return fail(h, BFSM_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(g.err));
     h->be.stream = (hipStream_t)stream;
     return BFSM_OK;
 }
 
 int bfsm_gain_partial(bfsm_handle h, const double* f_dev, void* stream) {
-    int rc = enter(h, stream);
-    if (rc) return rc;
-    if (!f_dev) return fail(h, BFSM_ERR_INVALID, "null f");
-    h->be.begin_eval();
-    if (h->p64) h->p64->gain_partial(f_dev); else h->p32->gain_partial(f_dev);
-    return check_hip(h, "bfsm_gain_partial");
+    if (!h) return BFSM_ERR_INVALID;
+    BFSM_GUARDED(h,
+        DeviceGuard g(h->desc.device);
+        int rc = enter(h, g, stream);
+        if (rc) return rc;
+        if (!f_dev) return fail(h, BFSM_ERR_INVALID, "null f");
+        h->be.begin_eval();
+        if (h->p64) h->p64->gain_partial(f_dev); else h->p32->gain_partial(f_dev);
+        return check_hip(h, "bfsm_gain_partial");
+    )
 }
 
 int bfsm_finish(bfsm_handle h, double* Q_dev, const double* f_dev, void* stream) {
-    int rc = enter(h, stream);
-    if (rc) return rc;
-    if (!f_dev || !Q_dev) return fail(h, BFSM_ERR_INVALID, "null f or Q");
-    if (h->p64) h->p64->finish(Q_dev, f_dev); else h->p32->finish(Q_dev, f_dev);
-    return check_hip(h, "bfsm_finish");
+    if (!h) return BFSM_ERR_INVALID;
+    BFSM_GUARDED(h,
+        DeviceGuard g(h->desc.device);
+        int rc = enter(h, g, stream);
+        if (rc) return rc;
+        if (!f_dev || !Q_dev) return fail(h, BFSM_ERR_INVALID, "null f or Q");
+        if (h->p64) h->p64->finish(Q_dev, f_dev); else h->p32->finish(Q_dev, f_dev);
+        return check_hip(h, "bfsm_finish");
+    )
 }
 
 int bfsm_finish_partial(bfsm_handle h, double* Q_dev, const double* f_dev, int with_loss, void* stream) {
-    int rc = enter(h, stream);
-    if (rc) return rc;
-    if (!f_dev || !Q_dev) return fail(h, BFSM_ERR_INVALID, "null f or Q");
-    if (h->p64) h->p64->finish(Q_dev, f_dev, with_loss != 0); else h->p32->finish(Q_dev, f_dev, with_loss != 0);
-    return check_hip(h, "bfsm_finish_partial");
+    if (!h) return BFSM_ERR_INVALID;
+    BFSM_GUARDED(h,
+        DeviceGuard g(h->desc.device);
+        int rc = enter(h, g, stream);
+        if (rc) return rc;
+        if (!f_dev || !Q_dev) return fail(h, BFSM_ERR_INVALID, "null f or Q");
+        if (h->p64) h->p64->finish(Q_dev, f_dev, with_loss != 0); else h->p32->finish(Q_dev, f_dev, with_loss != 0);
+        return check_hip(h, "bfsm_finish_partial");
+    )
 }
 
 int bfsm_collide_batch_async(bfsm_handle h, double* Q_dev, const double* f_dev, int n_batch, void* stream) {
-    int rc = enter(h, stream);
-    if (rc) return rc;
-    if (!f_dev || !Q_dev) return fail(h, BFSM_ERR_INVALID, "null f or Q");
-    if (!h->full_shard) return fail(h, BFSM_ERR_INVALID, "batched evaluation needs a handle that owns all directions");
-    const int cap = h->p64 ? h->p64->max_batch : h->p32->max_batch;
-    if (n_batch < 1 || n_batch > cap)
-        return fail(h, BFSM_ERR_INVALID, "n_batch must be in [1, max_batch of the descriptor]");
-    h->be.begin_eval();
-    if (h->p64) { h->p64->gain_partial(f_dev, n_batch); h->p64->finish(Q_dev, f_dev, true, n_batch); }
-    else { h->p32->gain_partial(f_dev, n_batch); h->p32->finish(Q_dev, f_dev, true, n_batch); }
-    return check_hip(h, "bfsm_collide_batch");
+    if (!h) return BFSM_ERR_INVALID;
+    BFSM_GUARDED(h,
+        DeviceGuard g(h->desc.device);
+        int rc = enter(h, g, stream);
+        if (rc) return rc;
+        if (!f_dev || !Q_dev) return fail(h, BFSM_ERR_INVALID, "null f or Q");
+        if (!h->full_shard) return fail(h, BFSM_ERR_INVALID, "batched evaluation needs a handle that owns all directions");
+        const int cap = h->p64 ? h->p64->max_batch : h->p32->max_batch;
+        if (n_batch < 1 || n_batch > cap)
+            return fail(h, BFSM_ERR_INVALID, "n_batch must be in [1, max_batch of the descriptor]");
+        h->be.begin_eval();
+        if (h->p64) { h->p64->gain_partial(f_dev, n_batch); h->p64->finish(Q_dev, f_dev, true, n_batch); }
+        else { h->p32->gain_partial(f_dev, n_batch); h->p32->finish(Q_dev, f_dev, true, n_batch); }
+        return check_hip(h, "bfsm_collide_batch");
+    )
 }
 
 int bfsm_collide_batch(bfsm_handle h, double* Q_dev, const double* f_dev, int n_batch) {
@@ -402,10 +459,13 @@ int bfsm_collide(bfsm_handle h, double* Q_dev, const double* f_dev) {
 
 int bfsm_synchronize(bfsm_handle h) {
     if (!h) return BFSM_ERR_INVALID;
-    hipError_t e = hipSetDevice(h->desc.device);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->be.stream);
-    if (e != hipSuccess) return fail(h, BFSM_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
-    return BFSM_OK;
+    BFSM_GUARDED(h,
+        DeviceGuard g(h->desc.device);
+        hipError_t e = g.err;
+        if (e == hipSuccess) e = hipStreamSynchronize(h->be.stream);
+        if (e != hipSuccess) return fail(h, BFSM_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+        return BFSM_OK;
+    )
 }
 
 void* bfsm_qhat_buffer(bfsm_handle h, size_t* n_elems, int* precision) {
@@ -416,15 +476,19 @@ void* bfsm_qhat_buffer(bfsm_handle h, size_t* n_elems, int* precision) {
 }
 
 int bfsm_fft3d(bfsm_handle h, void* data_dev, int batch, int sign) {
-    int rc = enter(h, nullptr);
-    if (rc) return rc;
-    if (!data_dev || batch < 1 || batch > 65535 || (sign != 1 && sign != -1))
-        return fail(h, BFSM_ERR_INVALID, "bad fft3d argument (null data, batch outside [1, 65535] or sign not +-1)");
-    if (h->p64) h->p64->fft3d((bfsm::cx<double>*)data_dev, batch, sign);
-    else h->p32->fft3d((bfsm::cx<float>*)data_dev, batch, sign);
-    rc = check_hip(h, "bfsm_fft3d");
-    if (rc) return rc;
-    return bfsm_synchronize(h);
+    if (!h) return BFSM_ERR_INVALID;
+    BFSM_GUARDED(h,
+        DeviceGuard g(h->desc.device);
+        int rc = enter(h, g, nullptr);
+        if (rc) return rc;
+        if (!data_dev || batch < 1 || batch > 65535 || (sign != 1 && sign != -1))
+            return fail(h, BFSM_ERR_INVALID, "bad fft3d argument (null data, batch outside [1, 65535] or sign not +-1)");
+        if (h->p64) h->p64->fft3d((bfsm::cx<double>*)data_dev, batch, sign);
+        else h->p32->fft3d((bfsm::cx<float>*)data_dev, batch, sign);
+        rc = check_hip(h, "bfsm_fft3d");
+        if (rc) return rc;
+        return bfsm_synchronize(h);
+    )
 }
 
 int bfsm_get_counters(bfsm_handle h, bfsm_counters* out) {
@@ -438,7 +502,9 @@ int bfsm_get_counters(bfsm_handle h, bfsm_counters* out) {
     c.exact_reductions = h->info.exact_reductions ? 1 : 0;
     c.antipodal_merged = h->info.antipodal ? 1 : 0;
     if (h->be.profile && !h->be.recs.empty()) {
-        hipError_t e = hipStreamSynchronize(h->be.stream);
+        DeviceGuard g(h->desc.device);
+        hipError_t e = g.err;
+        if (e == hipSuccess) e = hipStreamSynchronize(h->be.stream);
         if (e != hipSuccess) return fail(h, BFSM_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
         for (const auto& r : h->be.recs) {
             float ms = 0.f;
@@ -457,7 +523,7 @@ int bfsm_get_counters(bfsm_handle h, bfsm_counters* out) {
 
 int bfsm_destroy(bfsm_handle h) {
     if (!h) return BFSM_OK;
-    (void)hipSetDevice(h->desc.device);
+    DeviceGuard g(h->desc.device);
     (void)hipDeviceSynchronize();
     if (h->p64) { h->p64->destroy(); delete h->p64; }
     if (h->p32) { h->p32->destroy(); delete h->p32; }

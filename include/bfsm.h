@@ -10,7 +10,13 @@
  * Conventions (identical to the reference's CUDA backend, Collisions/CUDABoltzmannOperator.cu:119-220):
  *   - f and Q are DEVICE pointers to Nvx*Nvy*Nvz contiguous doubles, row-major [i][j][k], k (v_z) contiguous
  *     (maxwell_bkw_cuda.cu:119-126); they stay owned by the caller, all scratch is owned by the handle.
- *   - a handle is not re-entrant (shared scratch), like the reference object.
+ *   - a handle is not re-entrant (shared scratch), like the reference object: one thread at a time per handle, and
+ *     consecutive calls on one handle must be ordered on the device (same stream, or the caller's own events) because
+ *     they reuse the scratch.  Different handles are independent and may be driven from different threads / streams.
+ *   - every call makes the handle's device current for its own duration and restores the calling thread's current
+ *     device before it returns.
+ *   - the *_async entry points only enqueue kernels on the given stream (no allocation, no synchronisation), so
+ *     after one evaluation outside a capture they can be captured into a HIP graph.
  *   - functions never throw and never exit: they return BFSM_OK or an error code, and bfsm_last_error() returns a
  *     human-readable message (the reference prints and std::exit()s, CUDABoltzmannOperator.hpp:20-38; the C++
  *     wrapper restores that behaviour).
