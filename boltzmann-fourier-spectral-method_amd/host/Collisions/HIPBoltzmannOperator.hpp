@@ -35,7 +35,11 @@ public:
     void setDirectionShard(long long begin, long long end) { dir_begin_ = begin; dir_end_ = end; }
     void setMaxChunk(int n) { max_chunk_ = n; }
     void setProfiling(bool on) { flags_ = on ? (flags_ | BFSM_FLAG_PROFILE) : (flags_ & ~BFSM_FLAG_PROFILE); }
-    void setExactReductions(bool on) { flags_ = on ? (flags_ | BFSM_FLAG_EXACT_REDUCTIONS) : (flags_ & ~BFSM_FLAG_EXACT_REDUCTIONS); }
+    // Opt-in exact work reductions (include/bfsm.h: BFSM_FLAG_EXACT_REDUCTIONS; hermitian adds BFSM_FLAG_HERMITIAN).
+    void setExactReductions(bool on, bool hermitian = false) {
+        flags_ &= ~(BFSM_FLAG_EXACT_REDUCTIONS | BFSM_FLAG_HERMITIAN);
+        if (on) flags_ |= BFSM_FLAG_EXACT_REDUCTIONS | (hermitian ? BFSM_FLAG_HERMITIAN : 0);
+    }
     void setMaxBatch(int n) { max_batch_ = n; }
 
     void initialize() override;

@@ -2,7 +2,7 @@
 // of the collision operator; the reference stops at a single evaluation of Q).  SSP-RK3 (Shu-Osher) from the BKW
 // state at t0 to t1 with f resident on the device between evaluations; reports the error against the exact BKW
 // solution, mass / energy drift and the entropy at both ends.  Flags: --Nv --Ns --Ngl --t0 --t1 --steps
-// --exact-reductions --design-dir.
+// --exact-reductions --hermitian --design-dir.
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -48,7 +48,7 @@ static void bkw(int Nv, double L, double t, std::vector<double>& f) {
 int main(int argc, char** argv) {
     int Nv = 32, Ns = 32, Ngl = 16, steps = 10;
     double t0 = 5.5, t1 = 6.5;
-    bool exact = false;
+    bool exact = false, hermitian = false;
     std::string design_dir;
     for (int i = 1; i < argc; ++i) {
         auto val = [&](const char* name) -> const char* {
@@ -65,6 +65,7 @@ int main(int argc, char** argv) {
         else if ((v = val("--t1"))) t1 = std::atof(v);
         else if ((v = val("--design-dir"))) design_dir = v;
         else if (std::strcmp(argv[i], "--exact-reductions") == 0) exact = true;
+        else if (std::strcmp(argv[i], "--hermitian") == 0) exact = hermitian = true;
         else { std::cerr << "error: unknown argument " << argv[i] << "\n"; return EXIT_FAILURE; }
     }
     if (!design_dir.empty()) SphericalDesign::setDataDirectory(design_dir);
@@ -77,7 +78,7 @@ int main(int argc, char** argv) {
 
     BoltzmannOperator<HIP_Backend> op(std::make_shared<GaussLegendreQuadrature>(Ngl, 0, R),
                                       std::make_shared<SphericalDesign>(Ns), Nv, Nv, Nv, gamma, b_gamma, L);
-    op.setExactReductions(exact);
+    op.setExactReductions(exact, hermitian);
     op.initialize();
 
     double *f, *f1, *f2, *Q;

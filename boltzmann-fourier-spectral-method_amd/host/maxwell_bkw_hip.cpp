@@ -36,6 +36,7 @@ namespace {
 struct Args {
     int Nv = 32, Ns = 12, trials = 1, Ngl = -1, precision = 64, device = 0, warmup = 0;
     std::string input = "bkw", design_dir;
+    bool exact = false, hermitian = false;   // opt-in exact work reductions (include/bfsm.h)
 };
 
 bool take(int& i, int argc, char** argv, const char* name, std::string& out) {
@@ -58,6 +59,8 @@ Args parse(int argc, char** argv) {
         else if (take(i, argc, argv, "--warmup", v)) a.warmup = std::stoi(v);
         else if (take(i, argc, argv, "--input", v)) a.input = v;
         else if (take(i, argc, argv, "--design-dir", v)) a.design_dir = v;
+        else if (std::strcmp(argv[i], "--exact-reductions") == 0) a.exact = true;
+        else if (std::strcmp(argv[i], "--hermitian") == 0) a.exact = a.hermitian = true;
         else { std::cerr << "error: unknown argument " << argv[i] << "\n"; std::exit(EXIT_FAILURE); }
     }
     if (a.Ngl < 0) a.Ngl = a.Nv;   // reference behaviour (maxwell_bkw_cuda.cu:110)
@@ -126,6 +129,7 @@ int main(int argc, char** argv) {
     BoltzmannOperator<HIP_Backend> collision_operator(gl_quadrature, spherical_quadrature, Nv, Nv, Nv, gamma, b_gamma, L);
     collision_operator.setPrecision(a.precision);
     collision_operator.setDevice(a.device);
+    collision_operator.setExactReductions(a.exact, a.hermitian);
 
     using clk = std::chrono::steady_clock;
     const auto t_init = clk::now();

@@ -42,7 +42,7 @@
 
 int main(int argc, char** argv) {
     int Nv = 64, Ns = 48, Ngl = 16, trials = 5, gpus = 1, warmup = 2;
-    bool exact = false;
+    bool exact = false, hermitian = false;
     std::string design_dir;
     for (int i = 1; i < argc; ++i) {
         auto val = [&](const char* name) -> const char* {
@@ -59,6 +59,7 @@ int main(int argc, char** argv) {
         else if ((v = val("--warmup"))) warmup = std::atoi(v);
         else if ((v = val("--design-dir"))) design_dir = v;
         else if (std::strcmp(argv[i], "--exact-reductions") == 0) exact = true;
+        else if (std::strcmp(argv[i], "--hermitian") == 0) exact = hermitian = true;
         else { std::cerr << "error: unknown argument " << argv[i] << "\n"; return EXIT_FAILURE; }
     }
     int ndev = 0;
@@ -110,7 +111,7 @@ int main(int argc, char** argv) {
         HIP_OR_DIE(hipMemcpy(f_d[g], f_h.data(), G * sizeof(double), hipMemcpyHostToDevice));
         ops[g] = std::make_unique<BoltzmannOperator<HIP_Backend>>(gl, sph, Nv, Nv, Nv, gamma, b_gamma, L);
         ops[g]->setDevice(g);
-        ops[g]->setExactReductions(exact);
+        ops[g]->setExactReductions(exact, hermitian);
         const long long base = B / gpus, rem = B % gpus;        // contiguous, balanced shards
         const long long b0 = g * base + std::min<long long>(g, rem), b1 = b0 + base + (g < rem ? 1 : 0);
         ops[g]->setDirectionShard(b0, b1);

@@ -237,16 +237,17 @@ def test_cpp_driver_reproduces_published_norms(torch_cuda):
     exe = os.path.join(os.path.dirname(HERE), "boltzmann-fourier-spectral-method_amd", "maxwell_bkw_hip")
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", os.path.dirname(exe), "-s", "maxwell_bkw_hip"])
-    out = subprocess.run([exe, "--Nv", "32", "--Ns", "12", "-t", "3", "--design-dir",
-                          os.path.join(os.path.dirname(exe), "data", "sph_design")],
-                         capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0, out.stderr
-    text = out.stdout
-    assert "Run statistics for HIP" in text and "Total number of samples taken: 3" in text
-    got = {k: float(re.search(k + r" error: (\S+)", text).group(1)) for k in ("L1", "L2", "Linf")}
-    row = GOLD["published"][0]
-    for k in ("L1", "L2", "Linf"):
-        assert got[k] == pytest.approx(row[k], rel=2e-5), (k, got, text)     # std::cout prints 6 significant digits
+    for extra in ([], ["--hermitian"]):       # the opt-in exact reductions print the same norms
+        out = subprocess.run([exe, "--Nv", "32", "--Ns", "12", "-t", "3", "--design-dir",
+                              os.path.join(os.path.dirname(exe), "data", "sph_design")] + extra,
+                             capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+        text = out.stdout
+        assert "Run statistics for HIP" in text and "Total number of samples taken: 3" in text
+        got = {k: float(re.search(k + r" error: (\S+)", text).group(1)) for k in ("L1", "L2", "Linf")}
+        row = GOLD["published"][0]
+        for k in ("L1", "L2", "Linf"):
+            assert got[k] == pytest.approx(row[k], rel=2e-5), (k, got, text)     # std::cout prints 6 significant digits
 
 
 @pytest.mark.parametrize("nv,n_gl,n_sph", [(16, 8, 32), (32, 8, 48), (64, 2, 12)])
