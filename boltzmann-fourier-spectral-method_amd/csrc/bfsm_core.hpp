@@ -772,6 +772,7 @@ BFSM_HD void body_reduce(const ReduceParams<T>& prm, Ctx& ctx) {
     const int mx = mode_of(lx, N), my = mode_of(ly, N), mz = mode_of(lz, N);
     const int n2 = mx * mx + my * my + mz * mz;
     cx<T> q = {(T)0, (T)0};
+#pragma unroll 8   // eight slab loads in flight; the sum keeps its order
     for (int c = 0; c < prm.n_segs; ++c) {
         const cx<T> t = prm.slab[(size_t)ctx.by() * prm.slab_bstride + (size_t)c * G + idx];
         const T b1 = prm.beta1[(size_t)prm.segs[c].r * prm.n2stride + n2];

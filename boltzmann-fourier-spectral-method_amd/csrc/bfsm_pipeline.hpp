@@ -81,6 +81,17 @@ inline int validate_desc(const bfsm_desc& d, std::string& err) {
     return BFSM_OK;
 }
 
+// Workgroups a plane-parallel kernel (KA, KC) should offer: two 512-thread workgroups per CU at N >= 64 (what the
+// 65 KiB tiles allow); the small grids have 128- and 64-thread workgroups, so the same 16 waves per CU take 8 / 16
+// workgroups per CU.
+// A handle created for batches of nb distributions multiplies every grid by nb, so the per-distribution target shrinks
+// accordingly (never below 512: fewer, longer segments mean fewer slabs to write and reduce).
+inline int target_workgroups(int N, int max_batch = 1) {
+    const int single = N >= 64 ? 512 : (N == 32 ? 2048 : 1024);
+    const int nb = max_batch > 1 ? max_batch : 1;
+    return single / nb > 512 ? single / nb : 512;
+}
+
 inline PlanInfo make_plan(const bfsm_desc& d) {
     PlanInfo p;
     p.N = d.nvx;
@@ -108,7 +119,7 @@ inline PlanInfo make_plan(const bfsm_desc& d) {
     // Directions resident at once.  Sized for 288 GB of HBM: by default the whole shard (up to 1024 directions,
     // i.e. 8 GiB of A1'/A2' scratch at N=64 fp64) is one chunk, so an evaluation is ~8 launches.
     p.max_chunk = d.max_chunk > 0 ? d.max_chunk : 1024;
-    p.groups = (512 + p.N - 1) / p.N;           // >= 2 workgroups per CU on 256 CUs
+    p.groups = (target_workgroups(p.N, d.max_batch) + p.N - 1) / p.N;
     if (p.groups < 1) p.groups = 1;
     p.n2stride = 3 * (p.N / 2) * (p.N / 2) + 1;
     const long long len = p.dir_end - p.dir_begin;
@@ -335,7 +346,8 @@ struct Pipeline {
         }
         for (const Chunk& c : plan.chunks) {
             // KA's parallelism is planes x direction groups: keep >= 2 workgroups per CU when only N/2 + 1 planes run
-            const int groups_a = 512 / a_planes > 0 ? 512 / a_planes : 1;   // <= 512 workgroups: one resident wave of them
+            const int tw_ = target_workgroups(N, max_batch);
+            const int groups_a = tw_ / a_planes > 0 ? tw_ / a_planes : 1;   // <= target: one resident wave of workgroups
             const int per_group_a = (c.n + groups_a - 1) / groups_a;
             GainInvParams<T> ka{fhat, a1, a2, phx, phy, phz, tw, c.dir0, c.n, per_group_a, a_bs, a_planes};
             const int ga = (c.n + per_group_a - 1) / per_group_a;

@@ -106,7 +106,8 @@ def test_plan_chunks_and_segments_cover_shard_once():
         pos, seg_pos = 0, 0
         for ci, (n_seg, d0, n, per_group, seg0) in enumerate(chunks):
             assert d0 == pos and 1 <= n <= cap and seg0 == seg_pos
-            assert per_group * ((512 + nv - 1) // nv) >= n
+            groups = ((512 if nv >= 64 else 2048 if nv == 32 else 1024) + nv - 1) // nv
+            assert per_group * groups >= n
             inner = 0
             for (c, sd0, sn, r) in segs[seg0:seg0 + n_seg]:
                 assert c == ci and sd0 == inner and sn >= 1
@@ -114,7 +115,7 @@ def test_plan_chunks_and_segments_cover_shard_once():
                 assert g_first // n_sph == r == g_last // n_sph
                 inner += sn
             assert inner == n
-            assert n_seg >= min(n, (512 + nv - 1) // nv)
+            assert n_seg >= min(n, groups)
             pos += n
             seg_pos += n_seg
         assert pos == b1 - b0 and seg_pos == len(segs)
