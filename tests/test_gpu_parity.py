@@ -536,3 +536,19 @@ def test_evaluation_is_graph_capturable(torch_cuda, exact):
         op(Q, f)
         assert torch.equal(Q, Qg)
     op.destroy()
+
+
+def test_cpp_fft_benchmark_driver(torch_cuda):
+    """host/fft_benchmark_hip.cpp (format of the reference's cufft_benchmark.cu over bfsm_fft3d): the batched
+    forward + inverse round trip of the all-ones array is exact and the report has the reference's shape."""
+    import re
+    import subprocess
+    pkg = os.path.join(os.path.dirname(HERE), "boltzmann-fourier-spectral-method_amd")
+    exe = os.path.join(pkg, "fft_benchmark_hip")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", pkg, "-s", "fft_benchmark_hip"])
+    for extra in ([], ["--precision", "32"]):
+        out = subprocess.run([exe, "--Nv", "16", "--Ns", "6", "-t", "2"] + extra, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+        assert "Total number of samples taken: 2" in out.stdout and "Run statistics for HIP" in out.stdout
+        assert float(re.search(r"L1 error: (\S+)", out.stdout).group(1)) <= (1e-10 if not extra else 1e-2)
