@@ -13,7 +13,7 @@ K_COUNT = len(KERNEL_NAMES)
 
 # every symbol include/bfsm.h declares (checked by tests/test_capi_symbols.py)
 EXPORTED_SYMBOLS = (
-    "bfsm_create", "bfsm_collide", "bfsm_collide_async", "bfsm_collide_batch", "bfsm_collide_batch_async", "bfsm_gain_partial", "bfsm_finish", "bfsm_finish_partial",
+    "bfsm_create", "bfsm_collide", "bfsm_collide_async", "bfsm_collide_batch", "bfsm_collide_batch_async", "bfsm_gain_partial", "bfsm_finish", "bfsm_finish_partial", "bfsm_collide_partial_async",
     "bfsm_qhat_buffer",
     "bfsm_synchronize", "bfsm_fft3d", "bfsm_get_counters", "bfsm_destroy", "bfsm_last_error", "bfsm_backend_name",
     "bfsm_version",
@@ -90,6 +90,8 @@ def load_library(path=None):
     L.bfsm_finish.restype = ctypes.c_int
     L.bfsm_finish_partial.argtypes = [vp, vp, vp, ctypes.c_int, vp]
     L.bfsm_finish_partial.restype = ctypes.c_int
+    L.bfsm_collide_partial_async.argtypes = [vp, vp, vp, ctypes.c_int, vp]
+    L.bfsm_collide_partial_async.restype = ctypes.c_int
     L.bfsm_qhat_buffer.argtypes = [vp, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_int)]
     L.bfsm_qhat_buffer.restype = vp
     L.bfsm_synchronize.argtypes = [vp]

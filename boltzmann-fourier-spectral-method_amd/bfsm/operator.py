@@ -136,6 +136,12 @@ class HIPBoltzmannOperator:
         self._check(self._lib.bfsm_finish_partial(self._h, _ptr(Q), _ptr(f_in), 1 if with_loss else 0,
                                                   ctypes.c_void_p(stream)))
 
+    def collidePartial(self, Q, f_in, with_loss, stream=0):
+        """gainPartial + finishPartial as one call (slab reduce fused into the tail; qhatBuffer() is not updated)."""
+        self._require(f_in, Q)
+        self._check(self._lib.bfsm_collide_partial_async(self._h, _ptr(Q), _ptr(f_in), 1 if with_loss else 0,
+                                                         ctypes.c_void_p(stream)))
+
     def qhatBuffer(self):
         """(device pointer, n_elems, precision) of the partial Q_gain_hat owned by the handle."""
         n = ctypes.c_size_t()

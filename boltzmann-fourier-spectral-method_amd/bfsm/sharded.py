@@ -20,16 +20,18 @@ def sharded_step(op, qhat, Q, f, dist=None, stream=0, reduce_spectral=False, asy
     handle.wait() before it reads or reuses that Q.  Returns None when there is nothing to wait for.
     """
     multi = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
-    op.gainPartial(f, stream)
-    if not multi:
-        op.finish(Q, f, stream)
-    elif reduce_spectral:
-        dist.all_reduce(qhat)
-        op.finish(Q, f, stream)
-    else:
-        op.finishPartial(Q, f, dist.get_rank() == 0, stream)
+    if multi and not reduce_spectral:
+        if hasattr(op, "collidePartial"):      # one call: the library fuses the slab reduce into the tail
+            op.collidePartial(Q, f, dist.get_rank() == 0, stream)
+        else:
+            op.gainPartial(f, stream)
+            op.finishPartial(Q, f, dist.get_rank() == 0, stream)
         work = dist.all_reduce(Q, async_op=async_op)      # the single collective of an evaluation (sum)
         return work if async_op else None
+    op.gainPartial(f, stream)
+    if multi:
+        dist.all_reduce(qhat)
+    op.finish(Q, f, stream)
     return None
 
 

@@ -385,6 +385,14 @@ struct TailInvParams {       // tail step 1: plane inverse transforms of Q_hat a
     cx<T>* tg;               // [lx][y][z]
     cx<T>* tl;
     const cx<T>* tw;
+    // n_segs >= 0: the gain plane is formed here from the write-once slabs (the reduce of ReduceParams fused into
+    // the load, same summation order, qhat not touched); n_segs < 0: read it from qhat.
+    const cx<T>* slab;
+    const T* beta1;
+    const Segment* segs;
+    int n_segs;
+    int n2stride;
+    size_t slab_bstride;
 };
 
 template <typename T>
@@ -796,7 +804,30 @@ BFSM_HD void body_tail_inv(const TailInvParams<T>& prm, Ctx& ctx) {
     twr.load(prm.tw, u, ctx);
     cx<T> v[E];
     const size_t pbase = (size_t)ctx.bz() * N * N * N + (size_t)lxi * N * N;
-    if (!loss) {
+    if (!loss && prm.n_segs >= 0) {
+        // Q_hat plane = sum over slabs of beta1[r(slab)][|l|^2] * slab, in the order of body_reduce (bitwise the same)
+        const size_t G = (size_t)N * N * N;
+        const int mx = mode_of(lxi, N), my = mode_of(p, N);
+        int n2[E];
+#pragma unroll
+        for (int m = 0; m < E; ++m) {
+            const int mz = mode_of(u + TT * m, N);
+            n2[m] = mx * mx + my * my + mz * mz;
+            v[m] = {(T)0, (T)0};
+        }
+        const cx<T>* sl = prm.slab + (size_t)ctx.bz() * prm.slab_bstride + (size_t)lxi * N * N;
+#pragma unroll 2
+        for (int c = 0; c < prm.n_segs; ++c) {
+            const T* b1row = prm.beta1 + (size_t)prm.segs[c].r * prm.n2stride;
+#pragma unroll
+            for (int m = 0; m < E; ++m) {
+                const cx<T> t = sl[(size_t)c * G + (u + TT * m) * N + p];
+                const T b1 = b1row[n2[m]];
+                v[m].x += b1 * t.x;
+                v[m].y += b1 * t.y;
+            }
+        }
+    } else if (!loss) {
 #pragma unroll
         for (int m = 0; m < E; ++m) v[m] = prm.qhat[pbase + (u + TT * m) * N + p];
     } else {

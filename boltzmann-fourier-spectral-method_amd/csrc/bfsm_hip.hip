@@ -430,8 +430,8 @@ int bfsm_collide_batch_async(bfsm_handle h, double* Q_dev, const double* f_dev, 
         if (n_batch < 1 || n_batch > cap)
             return fail(h, BFSM_ERR_INVALID, "n_batch must be in [1, max_batch of the descriptor]");
         h->be.begin_eval();
-        if (h->p64) { h->p64->gain_partial(f_dev, n_batch); h->p64->finish(Q_dev, f_dev, true, n_batch); }
-        else { h->p32->gain_partial(f_dev, n_batch); h->p32->finish(Q_dev, f_dev, true, n_batch); }
+        if (h->p64) { const bool fu = h->p64->fuse_reduce(); h->p64->gain_partial(f_dev, n_batch, !fu); h->p64->finish(Q_dev, f_dev, true, n_batch, fu); }
+        else { const bool fu = h->p32->fuse_reduce(); h->p32->gain_partial(f_dev, n_batch, !fu); h->p32->finish(Q_dev, f_dev, true, n_batch, fu); }
         return check_hip(h, "bfsm_collide_batch");
     )
 }
@@ -446,9 +446,22 @@ int bfsm_collide_async(bfsm_handle h, double* Q_dev, const double* f_dev, void* 
     if (!h) return BFSM_ERR_INVALID;
     if (!h->full_shard)
         return fail(h, BFSM_ERR_INVALID, "bfsm_collide needs a handle that owns all directions; use gain_partial + reduce + finish");
-    int rc = bfsm_gain_partial(h, f_dev, stream);
-    if (rc) return rc;
-    return bfsm_finish(h, Q_dev, f_dev, stream);
+    return bfsm_collide_partial_async(h, Q_dev, f_dev, 1, stream);
+}
+
+int bfsm_collide_partial_async(bfsm_handle h, double* Q_dev, const double* f_dev, int with_loss, void* stream) {
+    if (!h) return BFSM_ERR_INVALID;
+    BFSM_GUARDED(h,
+        DeviceGuard g(h->desc.device);
+        int rc = enter(h, g, stream);
+        if (rc) return rc;
+        if (!f_dev || !Q_dev) return fail(h, BFSM_ERR_INVALID, "null f or Q");
+        h->be.begin_eval();
+        // gain kernels, then the tail; with few slabs the reduce is fused into its first kernel (qhat is not written then)
+        if (h->p64) { const bool fu = h->p64->fuse_reduce(); h->p64->gain_partial(f_dev, 1, !fu); h->p64->finish(Q_dev, f_dev, with_loss != 0, 1, fu); }
+        else { const bool fu = h->p32->fuse_reduce(); h->p32->gain_partial(f_dev, 1, !fu); h->p32->finish(Q_dev, f_dev, with_loss != 0, 1, fu); }
+        return check_hip(h, "bfsm_collide_partial");
+    )
 }
 
 int bfsm_collide(bfsm_handle h, double* Q_dev, const double* f_dev) {

@@ -329,7 +329,14 @@ struct Pipeline {
     // f_hat = FFT(f), then the gain term of this shard into qhat (partial Q_gain_hat, spectral layout).
     // nb distributions f_dev[nb][G] are processed by the same launches (grid.z / grid.y = batch member); all
     // per-distribution buffers are [nb][...].
-    void gain_partial(const double* f_dev, int nb = 1) {
+    // Fusing the slab reduce into the first tail kernel saves a launch and a pass over Q_hat, but that kernel has only
+    // N (x 2) workgroups, each walking all slabs: it pays for few slabs (a 1/8 shard of cfg3: 0.445 -> 0.439 ms per
+    // evaluation) and loses against the wide reduce kernel for many (cfg2, 64 slabs: 4.0 k -> 2.8 k evaluations/s).
+    bool fuse_reduce() const { return slab_count <= 8; }
+
+    // do_reduce = false leaves the slabs un-summed (qhat is not written): for callers that continue with
+    // finish(..., from_slabs = true) in the same call and never expose qhat.
+    void gain_partial(const double* f_dev, int nb = 1, bool do_reduce = true) {
         const int N = plan.N;
         const double Gc = (double)plan.G() * cbytes() * nb;
         const size_t G = plan.G();
@@ -379,19 +386,24 @@ struct Pipeline {
             be->mark(BFSM_K_GAIN_FWD, 1.0 * (double)slab_count * Gc);
             be->template launch<K::GainFwd, T>(N, (int)slab_count, nb, kc, N);
         }
-        ReduceParams<T> kr{slab, qhat, beta1, segs, (int)slab_count, plan.n2stride, s_bs};
-        be->mark(BFSM_K_REDUCE, ((double)slab_count + 1.0) * Gc);
-        be->template launch<K::Reduce, T>((int)((plan.G() + 255) / 256), nb, 1, kr, N);
+        if (do_reduce) {
+            ReduceParams<T> kr{slab, qhat, beta1, segs, (int)slab_count, plan.n2stride, s_bs};
+            be->mark(BFSM_K_REDUCE, ((double)slab_count + 1.0) * Gc);
+            be->template launch<K::Reduce, T>((int)((plan.G() + 255) / 256), nb, 1, kr, N);
+        }
     }
 
     // Loss term + final inverse transforms + combine  (CUDABoltzmannOperator.cu:193-216)
     // with_loss = false: Q = Re IFFT(qhat) only -- the partial result a rank contributes when the caller sums Q
     // itself (half the bytes of summing Q_hat) and another rank adds the loss term.
-    void finish(double* Q_dev, const double* f_dev, bool with_loss = true, int nb = 1) {
+    // from_slabs = true: the slab reduce is fused into the first tail kernel (after gain_partial(.., false)).
+    void finish(double* Q_dev, const double* f_dev, bool with_loss = true, int nb = 1, bool from_slabs = false) {
         const int N = plan.N;
         const double Gc = (double)plan.G() * cbytes() * nb;
-        TailInvParams<T> ta{qhat, fhat, beta2, tg, tl, tw};
-        be->mark(BFSM_K_TAIL, (with_loss ? 4.0 : 2.0) * Gc);
+        const size_t s_bs = (slab_count ? slab_count : 1) * plan.G();
+        TailInvParams<T> ta{qhat, fhat, beta2, tg, tl, tw, slab, beta1, segs, from_slabs ? (int)slab_count : -1,
+                            plan.n2stride, s_bs};
+        be->mark(BFSM_K_TAIL, ((with_loss ? 4.0 : 2.0) + (from_slabs ? (double)slab_count - 1.0 : 0.0)) * Gc);
         be->template launch<K::TailInv, T>(N, with_loss ? 2 : 1, nb, ta, N);
         TailLineParams<T> tb{tg, tl, f_dev, Q_dev, tw, with_loss ? 1 : 0};
         be->mark(BFSM_K_TAIL, (with_loss ? 3.0 : 1.5) * Gc);

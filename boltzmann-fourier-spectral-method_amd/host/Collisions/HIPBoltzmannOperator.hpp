@@ -54,6 +54,8 @@ public:
     void gainPartial(const double* f_in, void* stream = nullptr);
     void finish(double* Q, const double* f_in, void* stream = nullptr);
     void finishPartial(double* Q, const double* f_in, bool with_loss, void* stream = nullptr);
+    // gainPartial + finishPartial as one call (slab reduce fused into the tail; qhatBuffer() is not updated)
+    void collidePartial(double* Q, const double* f_in, bool with_loss, void* stream = nullptr);
     void* qhatBuffer(size_t* n_elems, int* precision) const;
     void synchronize();
     bfsm_counters counters() const;

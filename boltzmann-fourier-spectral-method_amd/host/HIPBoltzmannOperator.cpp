@@ -59,6 +59,10 @@ void BoltzmannOperator<HIP_Backend>::finishPartial(double* Q, const double* f_in
     check(bfsm_finish_partial(handle_, Q, f_in, with_loss ? 1 : 0, stream), "finishPartial");
 }
 
+void BoltzmannOperator<HIP_Backend>::collidePartial(double* Q, const double* f_in, bool with_loss, void* stream) {
+    check(bfsm_collide_partial_async(handle_, Q, f_in, with_loss ? 1 : 0, stream), "collidePartial");
+}
+
 void* BoltzmannOperator<HIP_Backend>::qhatBuffer(size_t* n_elems, int* precision) const {
     return bfsm_qhat_buffer(handle_, n_elems, precision);
 }

@@ -2,7 +2,8 @@
 //
 // New functionality (the reference is single-device): the B = M_gl * M_sph quadrature directions are sharded
 // contiguously over the devices; per evaluation every device computes its partial Q_gain_hat
-// (bfsm_gain_partial), inverse-transforms it (bfsm_finish_partial, device 0 also subtracts the loss term) and ONE
+// (bfsm_gain_partial), inverse-transforms it (bfsm_finish_partial; both in one bfsm_collide_partial_async call, device 0
+// also subtracts the loss term) and ONE
 // grouped ncclAllReduce sums the real Q (G doubles) on all devices.  Same flags and report as maxwell_bkw_hip
 // (reference: maxwell_bkw_cuda.cu:27-51,137-180) plus --gpus P.  bench.py does the same with one process per GPU.
 #include <hip/hip_runtime.h>
@@ -121,8 +122,7 @@ int main(int argc, char** argv) {
 
     auto evaluate = [&]() {
         for (int g = 0; g < gpus; ++g) {
-            ops[g]->gainPartial(f_d[g], streams[g]);
-            ops[g]->finishPartial(Q_d[g], f_d[g], g == 0, streams[g]);
+            ops[g]->collidePartial(Q_d[g], f_d[g], g == 0, streams[g]);   // gain_partial + finish_partial, fused
         }
         RCCL_OR_DIE(ncclGroupStart());
         for (int g = 0; g < gpus; ++g)

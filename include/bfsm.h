@@ -148,6 +148,11 @@ int bfsm_finish(bfsm_handle h, double* Q_dev, const double* f_dev, void* stream)
  *   <one sum all-reduce of Q (G doubles), by the caller>
  * Exactly one rank passes with_loss != 0. */
 int bfsm_finish_partial(bfsm_handle h, double* Q_dev, const double* f_dev, int with_loss, void* stream);
+/* The same two steps as ONE call, which lets the library fuse the slab reduce into the first tail kernel when the
+ * shard has few slabs (one launch and one pass over Q_hat fewer; bitwise the same Q).  The contents of
+ * bfsm_qhat_buffer() are unspecified after this call and after bfsm_collide / bfsm_collide_batch, which are this
+ * sequence with with_loss = 1; only bfsm_gain_partial defines them. */
+int bfsm_collide_partial_async(bfsm_handle h, double* Q_dev, const double* f_dev, int with_loss, void* stream);
 /* Device pointer to the (partial) Q_gain_hat: n_elems reals of `precision` bits (2*G, interleaved complex in the
  * library's spectral layout [lx][lz][ly]); the buffer the collective must sum in place. */
 void* bfsm_qhat_buffer(bfsm_handle h, size_t* n_elems, int* precision);

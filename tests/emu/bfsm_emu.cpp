@@ -195,12 +195,15 @@ int collide_t(const bfsm_desc* d, const double* f, double* Q, double* qhat_out, 
     int rc = p.init(*d, &be, err);
     if (rc) return rc;
     if (nb < 1 || nb > p.max_batch) return BFSM_ERR_INVALID;
-    p.gain_partial(f, nb);
+    // qhat requested: the two-call sequence (bfsm_gain_partial, bfsm_finish); otherwise the fused sequence of
+    // bfsm_collide / bfsm_collide_batch / bfsm_collide_partial_async (slab reduce inside the first tail kernel)
+    const bool fused = qhat_out == nullptr;   // (the library additionally fuses only shards with few slabs)
+    p.gain_partial(f, nb, !fused);
     if (qhat_out) {
         const size_t G = p.plan.G() * (size_t)nb;
         for (size_t i = 0; i < G; ++i) { qhat_out[2 * i] = (double)p.qhat[i].x; qhat_out[2 * i + 1] = (double)p.qhat[i].y; }
     }
-    if (Q) p.finish(Q, f, true, nb);
+    if (Q) p.finish(Q, f, true, nb, fused);
     p.destroy();
     return be.failed ? 99 : 0;
 }

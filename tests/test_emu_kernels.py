@@ -244,3 +244,16 @@ def test_hermitian_batch_and_shards(oracle):
         _, qh = E.collide(fs[1], gl, sph, GAMMA, B_GAMMA, L, 64, dir_range=rng_, want_Q=False, flags=EXACT | HERMITIAN)
         parts = parts + qh
     assert np.abs(parts - whole).max() <= 1e-12 * np.abs(whole).max()
+
+
+@pytest.mark.parametrize("nv,n_gl,n_sph,flags", [(16, 3, 12, 0), (32, 2, 6, 0), (16, 3, 12, EXACT)])
+def test_fused_reduce_tail_is_bitwise_the_two_call_sequence(oracle, nv, n_gl, n_sph, flags):
+    """bfsm_collide / bfsm_collide_batch / bfsm_collide_partial_async fuse the slab reduce into the first tail kernel;
+    the sum keeps the order of the reduce kernel, so Q is bitwise what gain_partial + finish give."""
+    f, _, L, _ = oracle.bkw(nv)
+    f = oracle.perturbed_input(f)
+    gl = oracle.gauss_legendre(n_gl, 0.0, R)
+    sph = oracle.spherical_design(n_sph)
+    Q2, _ = E.collide(f, gl, sph, GAMMA, B_GAMMA, L, 64, max_chunk=5, flags=flags)            # two calls
+    Q1 = E.collide_batch(f[None], gl, sph, GAMMA, B_GAMMA, L, 64, max_chunk=5, flags=flags)[0]   # fused
+    assert np.array_equal(Q1, Q2)

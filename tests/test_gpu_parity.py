@@ -552,3 +552,29 @@ def test_cpp_fft_benchmark_driver(torch_cuda):
         assert out.returncode == 0, out.stderr
         assert "Total number of samples taken: 2" in out.stdout and "Run statistics for HIP" in out.stdout
         assert float(re.search(r"L1 error: (\S+)", out.stdout).group(1)) <= (1e-10 if not extra else 1e-2)
+
+
+@pytest.mark.parametrize("nv,n_gl,n_sph,exact", [(16, 8, 32, False), (64, 2, 12, False), (32, 4, 12, True)])
+def test_fused_collide_is_bitwise_the_two_call_sequence(torch_cuda, nv, n_gl, n_sph, exact):
+    """bfsm_collide and bfsm_collide_partial_async (slab reduce fused into the tail) against bfsm_gain_partial +
+    bfsm_finish / bfsm_finish_partial on the same handle: same bits."""
+    import bfsm
+    torch = torch_cuda
+    f = torch.from_numpy(bfsm.perturbed_input(bfsm.bkw_solution(nv)[0])).cuda()
+    op = _make(bfsm, nv, n_gl, n_sph, exact=exact, hermitian=exact, max_chunk=7)
+    Qa, Qb = torch.empty_like(f), torch.empty_like(f)
+    op(Qa, f)                                   # fused
+    op.gainPartial(f)
+    op.finish(Qb, f)
+    torch.cuda.synchronize()
+    assert torch.equal(Qa, Qb)
+    op.destroy()
+    B = n_gl * n_sph
+    shard = _make(bfsm, nv, n_gl, n_sph, shard=(B // 3, B), exact=exact, hermitian=exact)
+    for with_loss in (False, True):
+        shard.collidePartial(Qa, f, with_loss)
+        shard.gainPartial(f)
+        shard.finishPartial(Qb, f, with_loss)
+        torch.cuda.synchronize()
+        assert torch.equal(Qa, Qb)
+    shard.destroy()

@@ -32,9 +32,14 @@ for P in (1, 2, 4, 8):
     op.setDirectionShard(*bfsm.shard_range(B, 0, P))
     op.initialize()
 
+    fused = os.environ.get("BFSM_SHARD_COST_TWO_CALLS") is None
+
     def step():
-        op.gainPartial(f, s)
-        op.finishPartial(Q, f, True, s)
+        if fused:
+            op.collidePartial(Q, f, True, s)       # what bfsm.sharded_step issues per evaluation
+        else:
+            op.gainPartial(f, s)
+            op.finishPartial(Q, f, True, s)
 
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < 0.3:
