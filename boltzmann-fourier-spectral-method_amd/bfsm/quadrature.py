@@ -67,12 +67,18 @@ class SphericalDesign:
             raise ValueError("Number of points N must be a positive integer")
         if N not in _DEGREE_OF:
             raise ValueError("Invalid value of N")
-        path = os.path.join(data_dir or os.environ.get("BFSM_DESIGN_DIR", _DATA_DIR),
-                            f"sym_design_t{_DEGREE_OF[N]:03d}_n{N:03d}.dat")
+        d = data_dir or os.environ.get("BFSM_DESIGN_DIR", _DATA_DIR)
+        path = os.path.join(d, f"sym_design_t{_DEGREE_OF[N]:03d}_n{N:03d}.dat")
+        header = 1
         if not os.path.exists(path):
-            raise RuntimeError("Could not open file " + path)
+            # the reference's own table of the same design (N rows of x y z, no header): lets BFSM_DESIGN_DIR point
+            # at the directory a user of the reference already has
+            alt = os.path.join(d, f"ss{_DEGREE_OF[N]:03d}.{N:03d}.txt")
+            if not os.path.exists(alt):
+                raise RuntimeError("Could not open file " + path + " (nor " + alt + ")")
+            path, header = alt, 0
         rows = [ln.split() for ln in open(path) if ln.strip() and not ln.startswith("#")]
-        pts = np.array([[float(v) for v in r] for r in rows[1:]], dtype=np.float64)
+        pts = np.array([[float(v) for v in r] for r in rows[header:]], dtype=np.float64)
         if pts.shape != (N, 3):
             raise RuntimeError(f"{path}: expected {N} points, found {pts.shape}")
         self._x, self._y, self._z = (np.ascontiguousarray(pts[:, k]) for k in range(3))

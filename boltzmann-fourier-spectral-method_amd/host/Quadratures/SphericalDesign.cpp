@@ -40,13 +40,23 @@ void SphericalDesign::load(int N, const std::string& dir) {
     if (N <= 0) throw std::invalid_argument("Number of points N must be a positive integer");
     const int t = degree_for(N);
     if (t == 0) throw std::invalid_argument("Invalid value of N");
+    // This package's own tables ("sym_design_tTTT_nNNN.dat": comments, a "t n" header, then x y z), or -- so that the
+    // directory a user of the reference already has can be used as it is -- the reference's table of the same design
+    // ("ssTTT.NNN.txt": N rows of x y z, SphericalDesign.cpp:12-24,38-46).
     char name[64];
     std::snprintf(name, sizeof(name), "sym_design_t%03d_n%03d.dat", t, N);
-    const std::string path = dir + "/" + name;
+    std::string path = dir + "/" + name;
     std::ifstream in(path);
-    if (!in.is_open()) throw std::runtime_error("Could not open file " + path);
-    std::string line;
     bool header_seen = false;
+    if (!in.is_open()) {
+        std::snprintf(name, sizeof(name), "ss%03d.%03d.txt", t, N);
+        const std::string alt = dir + "/" + name;
+        in.open(alt);
+        if (!in.is_open()) throw std::runtime_error("Could not open file " + path + " (nor " + alt + ")");
+        path = alt;
+        header_seen = true;            // the reference's tables have no header row
+    }
+    std::string line;
     while (std::getline(in, line)) {
         if (line.empty() || line[0] == '#') continue;
         std::istringstream row(line);

@@ -91,6 +91,14 @@ int main(int argc, char** argv) {
     threw = false;
     try { SphericalDesign bad(12, "/nonexistent/dir"); } catch (const std::runtime_error&) { threw = true; }
     CHECK(threw);
+    if (argc > 2) {   // a directory holding the same designs in the reference's table format (ssTTT.NNN.txt)
+        for (int N : {12, 48}) {
+            SphericalDesign a(N, data_dir), b(N, argv[2]);
+            for (int s = 0; s < N; ++s)
+                CHECK(a.getx()[s] == b.getx()[s] && a.gety()[s] == b.gety()[s] && a.getz()[s] == b.getz()[s] &&
+                      a.getWeights()[s] == b.getWeights()[s]);
+        }
+    }
     SphericalDesign::setDataDirectory(data_dir);
     CHECK(SphericalDesign(48).getNumberOfPoints() == 48);      // default-directory constructor honours the setter
 

@@ -11,6 +11,21 @@ def test_cpp_host_mirror(tmp_path):
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-I", os.path.join(PKG, "host"),
                            os.path.join(ROOT, "tests", "host", "test_host_mirror.cpp"),
                            os.path.join(PKG, "host", "Quadratures", "SphericalDesign.cpp"), "-o", exe])
-    out = subprocess.run([exe, os.path.join(PKG, "data", "sph_design")], capture_output=True, text=True, timeout=120)
+    # the same designs written in the reference's table format (N rows of "x y z", %24.16e, no header)
+    import sys
+    sys.path.insert(0, PKG)
+    import numpy as np
+    import bfsm
+    ref_dir = tmp_path / "ref_tables"
+    ref_dir.mkdir()
+    for N, t in ((12, 5), (48, 9)):
+        sd = bfsm.SphericalDesign(N)
+        with open(ref_dir / f"ss{t:03d}.{N:03d}.txt", "w") as fh:
+            for x, y, z in zip(sd.getx(), sd.gety(), sd.getz()):
+                fh.write("%25.16e%25.16e%25.16e\n" % (x, y, z))
+        again = bfsm.SphericalDesign(N, str(ref_dir))          # Python loader, reference format
+        assert np.array_equal(again.getx(), sd.getx()) and np.array_equal(again.getz(), sd.getz())
+    out = subprocess.run([exe, os.path.join(PKG, "data", "sph_design"), str(ref_dir)], capture_output=True, text=True,
+                         timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all host-mirror checks passed" in out.stdout
