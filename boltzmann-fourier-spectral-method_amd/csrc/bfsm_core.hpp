@@ -780,12 +780,20 @@ BFSM_HD void body_reduce(const ReduceParams<T>& prm, Ctx& ctx) {
     const int mx = mode_of(lx, N), my = mode_of(ly, N), mz = mode_of(lz, N);
     const int n2 = mx * mx + my * my + mz * mz;
     cx<T> q = {(T)0, (T)0};
-#pragma unroll 8   // eight slab loads in flight; the sum keeps its order
-    for (int c = 0; c < prm.n_segs; ++c) {
-        const cx<T> t = prm.slab[(size_t)ctx.by() * prm.slab_bstride + (size_t)c * G + idx];
+    const cx<T>* sl = prm.slab + (size_t)ctx.by() * prm.slab_bstride + idx;
+    auto add = [&](int c) {
+        const cx<T> t = sl[(size_t)c * G];
         const T b1 = prm.beta1[(size_t)prm.segs[c].r * prm.n2stride + n2];
         q.x += b1 * t.x;
         q.y += b1 * t.y;
+    };
+    if constexpr (N >= 64) {
+        // >= 1024 workgroups: enough threads to cover the latency, the rolled loop streams best (cfg3: 12 vs 16 us)
+        for (int c = 0; c < prm.n_segs; ++c) add(c);
+    } else {
+        // small grids: few workgroups and many slabs -- keep eight slab loads in flight (the sum keeps its order)
+#pragma unroll 8
+        for (int c = 0; c < prm.n_segs; ++c) add(c);
     }
     prm.qhat[(size_t)ctx.by() * G + idx] = q;
 }
