@@ -83,7 +83,17 @@ def cpu_baseline(w, seconds_target=15.0):
         O.collide(f_h, gl, sph, c["gamma"], c["b_gamma"], c["L"], dir_range=(0, n2), threads=threads)
         t1, n = time.perf_counter() - t0, n2
     evals_per_s = (n / B) / t1
+    # one thread, a handful of directions (fixed part measured separately with an empty shard and subtracted)
+    n1 = min(B, 8)
+    t0 = time.perf_counter()
+    O.collide(f_h, gl, sph, c["gamma"], c["b_gamma"], c["L"], dir_range=(0, n1), threads=1)
+    t_one = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    O.collide(f_h, gl, sph, c["gamma"], c["b_gamma"], c["L"], dir_range=(n1, n1), threads=1)     # empty shard: fixed part
+    t_fixed = time.perf_counter() - t0
+    per_dir_1 = max(t_one - t_fixed, 1e-9) / n1
     return {"value": evals_per_s, "unit": "evals/s", "cores": threads, "kind": "port",
+            "single_thread_value": 1.0 / (per_dir_1 * B + t_fixed),
             "sample": f"oracle/bfsm_oracle.c (own radix-2 FFT, fp64), first {n} of {B} directions of the same workload "
                       f"in {t1:.2f} s on {threads} OpenMP threads (= the CPUs this process may use: affinity mask capped "
                       f"by the cgroup quota), extrapolated linearly to B; FFTW3 is not installed in this image",
