@@ -578,3 +578,38 @@ def test_fused_collide_is_bitwise_the_two_call_sequence(torch_cuda, nv, n_gl, n_
         torch.cuda.synchronize()
         assert torch.equal(Qa, Qb)
     shard.destroy()
+
+
+def test_error_paths_through_the_c_abi(torch_cuda):
+    """Status codes + messages, never an exit or an exception across the boundary (include/bfsm.h conventions)."""
+    import ctypes
+    import bfsm
+    from bfsm import capi
+    torch = torch_cuda
+    L = capi.load_library()
+    op = _make(bfsm, 16, 2, 6, max_batch=2)
+    h = op._h
+    f = torch.zeros(2 * 16 ** 3, dtype=torch.float64, device="cuda")
+    Q = torch.empty_like(f)
+    null = ctypes.c_void_p(0)
+    assert L.bfsm_collide(h, null, ctypes.c_void_p(f.data_ptr())) == 1                       # BFSM_ERR_INVALID
+    assert b"null" in L.bfsm_last_error(h)
+    assert L.bfsm_collide_batch(h, ctypes.c_void_p(Q.data_ptr()), ctypes.c_void_p(f.data_ptr()), 3) == 1
+    assert b"n_batch" in L.bfsm_last_error(h)
+    assert L.bfsm_collide_batch(h, ctypes.c_void_p(Q.data_ptr()), ctypes.c_void_p(f.data_ptr()), 0) == 1
+    assert L.bfsm_fft3d(h, ctypes.c_void_p(f.data_ptr()), 1, 2) == 1                         # sign must be +-1
+    assert L.bfsm_fft3d(h, null, 1, 1) == 1
+    assert L.bfsm_collide(None, ctypes.c_void_p(Q.data_ptr()), ctypes.c_void_p(f.data_ptr())) == 1
+    assert L.bfsm_synchronize(None) == 1 and L.bfsm_destroy(None) == 0
+    # the handle is still usable after rejected calls
+    assert L.bfsm_collide_batch(h, ctypes.c_void_p(Q.data_ptr()), ctypes.c_void_p(f.data_ptr()), 2) == 0
+    assert torch.isfinite(Q).all()
+    op.destroy()
+    # a descriptor asking for a device that does not exist
+    one = np.ones(4)
+    dp = ctypes.POINTER(ctypes.c_double)
+    p = one.ctypes.data_as(dp)
+    bad = capi.Desc(16, 16, 16, 4, 4, p, p, p, p, p, p, 0.0, 1.0, 1.0, 64, 99, 0, 0, 0, 0)
+    hh = ctypes.c_void_p()
+    assert L.bfsm_create(ctypes.byref(bad), ctypes.byref(hh)) == 1 and not hh.value
+    assert b"device" in L.bfsm_last_error(None)
