@@ -287,6 +287,7 @@ struct GainInvParams {       // KA
     int per_group;           // directions handled by one workgroup (blockIdx.y)
     size_t a_bstride;        // elements between consecutive batch members (blockIdx.z) in a1 / a2
     int planes;              // lx planes stored per direction: N, or N/2 + 1 (indices 0..N/2) in the Hermitian mode
+    int warm_tables;         // != 0: touch the phase-table rows two iterations ahead (tables larger than an XCD's L2)
 };
 
 template <typename T>
@@ -516,7 +517,24 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
             v[m] = conj ? cmulc(fm, ph) : cmul(fm, ph);   // conj(alpha1) f_hat / G  :  alpha1 f_hat / G
             if constexpr (!KEEP) { if ((m & 3) == 3) ctx.sched_fence(); }   // at most 4 re-read points in flight
         }
+        // L2 warm-up of the phase-table rows of the direction after next.  The tables are read with ordinary loads and
+        // stay in L2 next to the nontemporal streams as long as they fit (<= ~4 MiB per XCD); for larger direction
+        // sets (config 5 on one GPU: 3 x 5.9 MiB) every row would be cold at the top of its iteration and stall all
+        // waves of the workgroup (measured: KA 8.7 -> 11 us per direction; with the warm-up 9.0 for any table size).
+        // One wave touches each 64-byte line of the phz / phy rows two iterations ahead; the values are only kept alive
+        // until the transform is done.  The host enables it where it pays: one workgroup per CU (N = 128) and tables
+        // beyond 3 MiB; with two workgroups per CU (N = 64) the other workgroup already covers the miss.
+        T warm = (T)0;
+        constexpr int EPL = 64 / (int)sizeof(cx<T>), LINES = N / EPL;       // entries per line, lines per row
+        const bool warming = (N % 64 == 0) && 2 * LINES <= 64 && prm.warm_tables != 0 && u == 0 && j + 2 < j_end && (j & 1) == 0;
+        if (warming) {
+            const size_t bw = (size_t)(prm.dir0 + ((j + 2) >> 1));
+            const int l = tid % 64;
+            const cx<T>* row = (l < LINES) ? prm.phz : prm.phy;
+            warm = row[bw * N + (size_t)(l % LINES) * EPL].x;
+        }
         fft_tile<N, +1, T>(v, lds, p, u, twr, ctx);
+        if (warming) ctx.keep_alive(warm);
         cx<T>* dst = (conj ? prm.a2 : prm.a1) + bz * prm.a_bstride + ((size_t)d * prm.planes + lxi) * N * N;
 #pragma unroll
         for (int m = 0; m < E; ++m)   // [y = u + T m][z = p]

@@ -28,6 +28,9 @@ struct DevCtx {
     __device__ __forceinline__ void sync() const { __syncthreads(); }
     // nothing is scheduled across this point (bounds how many loads the compiler keeps in flight, i.e. registers)
     __device__ __forceinline__ void sched_fence() const { __builtin_amdgcn_sched_barrier(0); }
+    // keeps a loaded value (and therefore its load) alive up to this point without using it
+    template <class T>
+    __device__ __forceinline__ void keep_alive(T v) const { asm volatile("" ::"v"(v)); }
     // a wave-uniform value the optimiser may not reason about: loads addressed through it are neither hoisted out of
     // loops nor merged, so they occupy SGPRs only where they are used
     __device__ __forceinline__ int opaque(int v) const {

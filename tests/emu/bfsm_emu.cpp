@@ -44,6 +44,7 @@ struct EmuCtx {
     void sync();       // workgroup barrier
     void sched_fence() const {}   // compiler scheduling hint on the device; nothing to do on the host
     int opaque(int v) const { return v; }
+    template <class T> void keep_alive(T) const {}
     template <class U> U* uniform_ptr(U* p) const { return p; }
     void wave_sync();  // ordering point inside one wave of 64 threads
 };

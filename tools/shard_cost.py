@@ -20,8 +20,6 @@ nv, n_gl, n_sph, prec = w["nv"], w["n_gl"], w["n_sph"], w["precision"]
 B = n_gl * n_sph
 c = bfsm.reference_constants()
 f = torch.from_numpy(bfsm.bkw_solution(nv)[0]).cuda()
-if prec == 32:
-    f = f.float()
 Q = torch.empty_like(f)
 s = torch.cuda.current_stream().cuda_stream
 base = None
@@ -29,7 +27,7 @@ for P in (1, 2, 4, 8):
     op = bfsm.HIPBoltzmannOperator(bfsm.GaussLegendreQuadrature(n_gl, 0.0, c["R"]), bfsm.SphericalDesign(n_sph),
                                    nv, nv, nv, c["gamma"], c["b_gamma"], c["L"])
     op.setPrecision(prec)
-    op.setDirectionShard(*bfsm.shard_range(B, 0, P))
+    op.setDirectionShard(*bfsm.shard_range(B, min(int(os.environ.get('BFSM_SHARD_COST_RANK', '0')), P - 1), P))
     op.initialize()
 
     fused = os.environ.get("BFSM_SHARD_COST_TWO_CALLS") is None
