@@ -137,7 +137,15 @@ inline PlanInfo make_plan(const bfsm_desc& d) {
             const long long g0 = p.dir_begin + o, g1 = g0 + c.n;
             const int r_first = (int)(g0 / p.sph_eff), r_last = (int)((g1 - 1) / p.sph_eff);
             const int runs = r_last - r_first + 1;
-            const int cuts = (p.groups + runs - 1) / runs;
+            int cuts = (p.groups + runs - 1) / runs;
+            // KC runs N x segments workgroups; with the large tiles only `resident` of them fit the GPU at once
+            // (one per CU at N = 128, two at N = 64), so a segment count that is not a multiple of resident / N leaves
+            // a partly empty last round (config 5: 5 runs -> 640 workgroups = 2.5 rounds; 10 segments = 5 full rounds)
+            const int resident = p.N >= 128 ? 256 : (p.N == 64 ? 512 : 0);
+            if (resident > 0 && resident % p.N == 0) {
+                const int unit = resident / p.N;
+                for (int extra = 0; extra < unit && (runs * cuts) % unit != 0; ++extra) ++cuts;
+            }
             for (int r = r_first; r <= r_last; ++r) {
                 long long a0 = (long long)r * p.sph_eff, a1 = a0 + p.sph_eff;
                 if (a0 < g0) a0 = g0;
