@@ -257,3 +257,47 @@ def test_fused_reduce_tail_is_bitwise_the_two_call_sequence(oracle, nv, n_gl, n_
     Q2, _ = E.collide(f, gl, sph, GAMMA, B_GAMMA, L, 64, max_chunk=5, flags=flags)            # two calls
     Q1 = E.collide_batch(f[None], gl, sph, GAMMA, B_GAMMA, L, 64, max_chunk=5, flags=flags)[0]   # fused
     assert np.array_equal(Q1, Q2)
+
+
+def test_randomised_plans_against_the_oracle(oracle):
+    """Seeded sweep over small shapes the hand-picked cases do not hit: single radial node, shards that start and end
+    inside a radial node, chunk sizes that divide nothing, every mode -- each shard's partial Q_gain_hat against the
+    oracle's for the same direction range (plan / segment / slab bookkeeping is what varies here)."""
+    rng = np.random.default_rng(20261004)
+    f, _, L, _ = oracle.bkw(16)
+    f = oracle.perturbed_input(f)
+    for case in range(36):
+        n_gl = int(rng.integers(1, 5))
+        n_sph = int(rng.choice([6, 12, 32]))
+        B = n_gl * n_sph
+        flags = int(rng.choice([0, EXACT, EXACT | HERMITIAN]))
+        max_chunk = int(rng.choice([0, 1, 3, 5, 7, 11]))
+        if rng.random() < 0.5:
+            lo = int(rng.integers(0, B))
+            hi = int(rng.integers(lo, B + 1))
+        else:
+            lo, hi = 0, B
+        if flags and (lo, hi) != (0, B):
+            # merged (antipodal) directions: a shard is given in full directions and maps proportionally; compare the
+            # sum of a two-way split with the whole instead of a direction range of the oracle
+            mid = int(rng.integers(0, B + 1))
+            gl = oracle.gauss_legendre(n_gl, 0.0, R)
+            sph = oracle.spherical_design(n_sph)
+            whole = oracle.collide(f, gl, sph, GAMMA, B_GAMMA, L, return_qhat=True)[1]
+            parts = sum(E.collide(f, gl, sph, GAMMA, B_GAMMA, L, 64, dir_range=r, max_chunk=max_chunk, want_Q=False,
+                                  flags=flags)[1] for r in ((0, mid), (mid, B)) if r[0] != r[1])
+            assert np.abs(parts - whole).max() <= 1e-12 * np.abs(whole).max(), (case, n_gl, n_sph, flags, max_chunk, mid)
+            continue
+        gl = oracle.gauss_legendre(n_gl, 0.0, R)
+        sph = oracle.spherical_design(n_sph)
+        rng_ = (lo, hi) if (lo, hi) != (0, B) else (0, 0)
+        want_Q = rng_ == (0, 0)
+        Q, qh = E.collide(f, gl, sph, GAMMA, B_GAMMA, L, 64, dir_range=rng_, max_chunk=max_chunk, want_Q=want_Q, flags=flags)
+        if lo == hi:
+            assert np.all(qh == 0)
+            continue
+        ref = oracle.collide(f, gl, sph, GAMMA, B_GAMMA, L, dir_range=(lo, hi), return_qhat=True)
+        scale = np.abs(oracle.collide(f, gl, sph, GAMMA, B_GAMMA, L, return_qhat=True)[1]).max()
+        assert np.abs(qh - ref[1]).max() <= 1e-12 * scale, (case, n_gl, n_sph, flags, max_chunk, lo, hi)
+        if want_Q:
+            assert np.abs(Q - ref[0]).max() <= 1e-12 * np.abs(ref[0]).max(), (case, n_gl, n_sph, flags, max_chunk)
