@@ -613,3 +613,39 @@ def test_error_paths_through_the_c_abi(torch_cuda):
     hh = ctypes.c_void_p()
     assert L.bfsm_create(ctypes.byref(bad), ctypes.byref(hh)) == 1 and not hh.value
     assert b"device" in L.bfsm_last_error(None)
+
+
+def test_randomised_plans_against_the_oracle(torch_cuda, oracle):
+    """Seeded sweep on the hardware: grid size, quadrature sizes, direction shard, chunk size, mode and batch size vary;
+    every case is compared with the oracle (whole evaluations) or with the sum rule of shards."""
+    import bfsm
+    torch = torch_cuda
+    rng = np.random.default_rng(4242)
+    fs = {nv: bfsm.perturbed_input(bfsm.bkw_solution(nv)[0]) for nv in (16, 32)}
+    for case in range(30):
+        nv = int(rng.choice([16, 32]))
+        n_gl = int(rng.integers(1, 6))
+        n_sph = int(rng.choice([6, 12, 32, 48]))
+        B = n_gl * n_sph
+        mode = int(rng.integers(0, 3))
+        exact, herm = mode >= 1, mode == 2
+        max_chunk = int(rng.choice([0, 1, 3, 7, 13, 50]))
+        f_h = fs[nv]
+        ref = _oracle(oracle, f_h, n_gl, n_sph)
+        tag = (case, nv, n_gl, n_sph, mode, max_chunk)
+        if rng.random() < 0.5:
+            op = _make(bfsm, nv, n_gl, n_sph, exact=exact, hermitian=herm, max_chunk=max_chunk)
+            got = _collide(torch, op, f_h)
+            op.destroy()
+        else:                                   # two or three shards, default (real-Q) combination
+            cuts = sorted(set([0, B] + [int(c) for c in rng.integers(0, B + 1, size=2)]))
+            f = torch.from_numpy(f_h).cuda()
+            got = np.zeros_like(f_h)
+            for i, (lo, hi) in enumerate(zip(cuts[:-1], cuts[1:])):
+                op = _make(bfsm, nv, n_gl, n_sph, shard=(lo, hi), exact=exact, hermitian=herm, max_chunk=max_chunk)
+                Qr = torch.empty_like(f)
+                op.collidePartial(Qr, f, i == 0)
+                torch.cuda.synchronize()
+                got += Qr.cpu().numpy()
+                op.destroy()
+        assert np.abs(got - ref).max() <= TOL64 * np.abs(ref).max(), tag
