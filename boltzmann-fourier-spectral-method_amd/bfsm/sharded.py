@@ -1,8 +1,10 @@
-"""Sharded (multi-GPU) evaluation: quadrature directions split contiguously over ranks, ONE sum all-reduce of the
-partial Q_gain_hat per evaluation (RCCL over xGMI when the process group is "nccl"), tail replicated on every rank.
+"""Sharded (multi-GPU) evaluation: quadrature directions split contiguously over ranks and ONE sum all-reduce per
+evaluation (RCCL over xGMI when the process group is "nccl") -- of the real Q by default (every rank transforms its
+own partial sum), or of the complex partial Q_gain_hat with the tail replicated on every rank.
 
-`op` is anything with gainPartial(f, stream) / finish(Q, f, stream) -- the HIP operator on a GPU box, or the
-host-emulated operator in the world-size-2 gloo tests.  `qhat` is a tensor view of the operator's partial-sum buffer.
+`op` is anything with gainPartial(f, stream) / finish(Q, f, stream) / finishPartial(Q, f, with_loss, stream) and,
+optionally, collidePartial(Q, f, with_loss, stream) -- the HIP operator on a GPU box, or the host-emulated operator
+in the world-size-2 gloo tests.  `qhat` is a tensor view of the operator's partial-sum buffer.
 """
 
 
