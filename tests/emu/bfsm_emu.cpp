@@ -189,7 +189,7 @@ struct EmuBackend {
 };
 
 template <typename T>
-int collide_t(const bfsm_desc* d, const double* f, double* Q, double* qhat_out, int nb) {
+int collide_t(const bfsm_desc* d, const double* f, double* Q, double* qhat_out, int nb, bool with_loss = true) {
     EmuBackend be;
     bfsm::Pipeline<T, EmuBackend> p;
     std::string err;
@@ -204,7 +204,7 @@ int collide_t(const bfsm_desc* d, const double* f, double* Q, double* qhat_out, 
         const size_t G = p.plan.G() * (size_t)nb;
         for (size_t i = 0; i < G; ++i) { qhat_out[2 * i] = (double)p.qhat[i].x; qhat_out[2 * i + 1] = (double)p.qhat[i].y; }
     }
-    if (Q) p.finish(Q, f, true, nb, fused);
+    if (Q) p.finish(Q, f, with_loss, nb, fused);
     p.destroy();
     return be.failed ? 99 : 0;
 }
@@ -262,6 +262,15 @@ int bfsm_emu_collide_batch(const bfsm_desc* d, const double* f, double* Q, doubl
     if (rc) return rc;
     return d->precision == BFSM_F64 ? emu::collide_t<double>(d, f, Q, qhat_out, n_batch)
                                     : emu::collide_t<float>(d, f, Q, qhat_out, n_batch);
+}
+
+// Emulated bfsm_collide_partial_async on a direction shard: fused gain + tail, with or without the loss term.
+int bfsm_emu_collide_partial(const bfsm_desc* d, const double* f, double* Q, int with_loss) {
+    std::string err;
+    int rc = bfsm::validate_desc(*d, err);
+    if (rc) return rc;
+    return d->precision == BFSM_F64 ? emu::collide_t<double>(d, f, Q, nullptr, 1, with_loss != 0)
+                                    : emu::collide_t<float>(d, f, Q, nullptr, 1, with_loss != 0);
 }
 
 int bfsm_emu_collide(const bfsm_desc* d, const double* f, double* Q, double* qhat_out) {

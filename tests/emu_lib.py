@@ -146,3 +146,24 @@ def collide_batch(fs, gl, sph, gamma, b_gamma, L, precision=64, max_chunk=0, fla
     if rc:
         raise RuntimeError(f"bfsm_emu_collide_batch rc={rc}")
     return Q
+
+
+class EmuOperatorFused(EmuOperator):
+    """The same with collidePartial (the one-call form bfsm.sharded_step prefers when the operator offers it)."""
+
+    def collidePartial(self, Q, f, with_loss, stream=0):
+        import torch
+        L = lib()
+        dp = ctypes.POINTER(ctypes.c_double)
+        if not hasattr(L.bfsm_emu_collide_partial, "_typed"):
+            from bfsm import capi
+            L.bfsm_emu_collide_partial.argtypes = [ctypes.POINTER(capi.Desc), dp, dp, ctypes.c_int]
+            L.bfsm_emu_collide_partial.restype = ctypes.c_int
+            L.bfsm_emu_collide_partial._typed = True
+        d, keep = make_desc(self.nv, self.gl, self.sph, *self.args, 64, self.dir_range, self.max_chunk)
+        fh = np.ascontiguousarray(f.numpy(), dtype=np.float64)
+        out = np.empty(self.nv ** 3)
+        rc = L.bfsm_emu_collide_partial(ctypes.byref(d), fh.ctypes.data_as(dp), out.ctypes.data_as(dp), 1 if with_loss else 0)
+        if rc:
+            raise RuntimeError(f"bfsm_emu_collide_partial rc={rc}")
+        Q.copy_(torch.from_numpy(out))

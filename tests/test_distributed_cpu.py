@@ -37,7 +37,10 @@ def _worker(rank, world, port, nv, n_gl, n_sph, out_dir, spectral):
     gl = O.gauss_legendre(n_gl, 0.0, c["R"])
     sph = O.spherical_design(n_sph)
     shard = bfsm.shard_range(n_gl * n_sph, rank, world)
-    op = E.EmuOperator(nv, gl, sph, c["gamma"], c["b_gamma"], c["L"], dir_range=shard, max_chunk=5)
+    cls = E.EmuOperatorFused if spectral == "fused" else E.EmuOperator
+    op = cls(nv, gl, sph, c["gamma"], c["b_gamma"], c["L"], dir_range=shard, max_chunk=5)
+    if spectral == "fused":
+        spectral = False        # default route, through collidePartial
     f = torch.from_numpy(f_h.reshape(-1).copy())
     Q = torch.empty_like(f)
     if spectral == "overlap":
@@ -65,7 +68,7 @@ def _worker(rank, world, port, nv, n_gl, n_sph, out_dir, spectral):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,spectral", [(2, False), (3, False), (2, True), (2, "overlap")])
+@pytest.mark.parametrize("world,spectral", [(2, False), (3, False), (2, True), (2, "overlap"), (2, "fused")])
 def test_sharded_step_over_gloo(tmp_path, world, spectral):
     import torch.multiprocessing as mp
     nv, n_gl, n_sph = 16, 3, 12
