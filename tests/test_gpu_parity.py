@@ -649,3 +649,24 @@ def test_randomised_plans_against_the_oracle(torch_cuda, oracle):
                 got += Qr.cpu().numpy()
                 op.destroy()
         assert np.abs(got - ref).max() <= TOL64 * np.abs(ref).max(), tag
+
+
+def test_full_config5_against_the_analytic_bkw_collision_term(torch_cuda):
+    """Config 5 at full size (N=128, M_gl=30, 192-point design, B=5760): the spectral method is converged there, so
+    the fp64 path must reproduce the analytic BKW collision term to rounding level, and the single-precision variant
+    must agree with it to fp32 rounding (known-answer test at BASELINE.json's largest size, both precisions)."""
+    import bfsm
+    torch = torch_cuda
+    nv, n_gl, n_sph = 128, 30, 192
+    f_h, q_exact, _, dv = bfsm.bkw_solution(nv)
+    f = torch.from_numpy(f_h).cuda()
+    out = {}
+    for prec in (64, 32):
+        op = _make(bfsm, nv, n_gl, n_sph, prec)
+        Q = torch.empty_like(f)
+        op(Q, f)
+        out[prec] = Q.cpu().numpy()
+        op.destroy()
+    l2 = float(np.sqrt(((out[64] - q_exact) ** 2).sum() * dv ** 3))
+    assert l2 <= 5e-15, l2                                                    # measured 3.3e-16
+    assert np.abs(out[32] - out[64]).max() <= 1e-5 * np.abs(out[64]).max()      # measured 1.1e-6
