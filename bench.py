@@ -25,6 +25,9 @@ import os
 import sys
 import time
 
+# the host driver of this pool only supports dmabuf IPC; RCCL between processes needs this before HIP initialises
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "boltzmann-fourier-spectral-method_amd"))
 
