@@ -1,13 +1,12 @@
 // maxwell_bkw_hip_multi -- the BKW driver on P MI355X GPUs of one node, single process, RCCL over xGMI.
 //
-// New functionality (the reference is single-device): the B = M_gl * M_sph quadrature directions are sharded
-// contiguously over the devices; per evaluation every device computes its partial Q_gain_hat
-// (bfsm_gain_partial), inverse-transforms it (bfsm_finish_partial; both in one bfsm_collide_partial_async call, device 0
-// also subtracts the loss term) and ONE
-// grouped ncclAllReduce sums the real Q (G doubles) on all devices.  Same flags and report as maxwell_bkw_hip
-// (reference: maxwell_bkw_cuda.cu:27-51,137-180) plus --gpus P.  bench.py does the same with one process per GPU.
+// The reference's driver (maxwell_bkw_cuda.cu:27-51,137-180) with the backend tag changed to HIP_MultiGPU_Backend:
+// f and Q live on the first device, `collision_operator(Q, f)` is one blocking call, and the operator class
+// (Collisions/HIPMultiGPUBoltzmannOperator.hpp) shards the B = M_gl * M_sph quadrature directions over the devices,
+// broadcasts f, and sums the partial results with ONE grouped RCCL reduce.  Same flags and report as maxwell_bkw_hip
+// plus --gpus P (and --force-rccl: use the collectives even with one device).  bench.py does the same with one
+// process per GPU.
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
 
 #include <chrono>
 #include <cmath>
@@ -18,7 +17,7 @@
 #include <string>
 #include <vector>
 
-#include "Collisions/HIPBoltzmannOperator.hpp"
+#include "Collisions/HIPMultiGPUBoltzmannOperator.hpp"
 #include "Quadratures/GaussLegendre.hpp"
 #include "Quadratures/SphericalDesign.hpp"
 #include "Utilities/constants.hpp"
@@ -32,18 +31,9 @@
             std::exit(EXIT_FAILURE);                                                                              \
         }                                                                                                         \
     } while (0)
-#define RCCL_OR_DIE(call)                                                                                          \
-    do {                                                                                                          \
-        ncclResult_t r_ = (call);                                                                                 \
-        if (r_ != ncclSuccess) {                                                                                  \
-            std::cerr << "RCCL Error: " << ncclGetErrorString(r_) << " at " << __FILE__ << ":" << __LINE__ << "\n"; \
-            std::exit(EXIT_FAILURE);                                                                              \
-        }                                                                                                         \
-    } while (0)
-
 int main(int argc, char** argv) {
     int Nv = 64, Ns = 48, Ngl = 16, trials = 5, gpus = 1, warmup = 2;
-    bool exact = false, hermitian = false;
+    bool exact = false, hermitian = false, force_rccl = false;
     std::string design_dir;
     for (int i = 1; i < argc; ++i) {
         auto val = [&](const char* name) -> const char* {
@@ -61,6 +51,7 @@ int main(int argc, char** argv) {
         else if ((v = val("--design-dir"))) design_dir = v;
         else if (std::strcmp(argv[i], "--exact-reductions") == 0) exact = true;
         else if (std::strcmp(argv[i], "--hermitian") == 0) exact = hermitian = true;
+        else if (std::strcmp(argv[i], "--force-rccl") == 0) force_rccl = true;
         else { std::cerr << "error: unknown argument " << argv[i] << "\n"; return EXIT_FAILURE; }
     }
     int ndev = 0;
@@ -96,43 +87,22 @@ int main(int argc, char** argv) {
 
     std::vector<int> devs(gpus);
     for (int g = 0; g < gpus; ++g) devs[g] = g;
-    std::vector<ncclComm_t> comms(gpus);
-    RCCL_OR_DIE(ncclCommInitAll(comms.data(), gpus, devs.data()));
+    HIP_OR_DIE(hipSetDevice(devs[0]));
+    double *f_d = nullptr, *Q_d = nullptr;            // on the first device, like the reference's driver (cu:119-126)
+    HIP_OR_DIE(hipMalloc(reinterpret_cast<void**>(&f_d), G * sizeof(double)));
+    HIP_OR_DIE(hipMalloc(reinterpret_cast<void**>(&Q_d), G * sizeof(double)));
+    HIP_OR_DIE(hipMemcpy(f_d, f_h.data(), G * sizeof(double), hipMemcpyHostToDevice));
 
-    std::vector<double*> f_d(gpus), Q_d(gpus);
-    std::vector<hipStream_t> streams(gpus);
-    std::vector<std::unique_ptr<BoltzmannOperator<HIP_Backend>>> ops(gpus);
     using clk = std::chrono::steady_clock;
     const auto t_init = clk::now();
-    for (int g = 0; g < gpus; ++g) {
-        HIP_OR_DIE(hipSetDevice(g));
-        HIP_OR_DIE(hipStreamCreate(&streams[g]));
-        HIP_OR_DIE(hipMalloc(reinterpret_cast<void**>(&f_d[g]), G * sizeof(double)));
-        HIP_OR_DIE(hipMalloc(reinterpret_cast<void**>(&Q_d[g]), G * sizeof(double)));
-        HIP_OR_DIE(hipMemcpy(f_d[g], f_h.data(), G * sizeof(double), hipMemcpyHostToDevice));
-        ops[g] = std::make_unique<BoltzmannOperator<HIP_Backend>>(gl, sph, Nv, Nv, Nv, gamma, b_gamma, L);
-        ops[g]->setDevice(g);
-        ops[g]->setExactReductions(exact, hermitian);
-        const long long base = B / gpus, rem = B % gpus;        // contiguous, balanced shards
-        const long long b0 = g * base + std::min<long long>(g, rem), b1 = b0 + base + (g < rem ? 1 : 0);
-        ops[g]->setDirectionShard(b0, b1);
-        ops[g]->initialize();
-    }
+    BoltzmannOperator<HIP_MultiGPU_Backend> collision_operator(gl, sph, Nv, Nv, Nv, gamma, b_gamma, L);
+    collision_operator.setDevices(devs);
+    collision_operator.setExactReductions(exact, hermitian);
+    collision_operator.setForceCollectives(force_rccl);
+    collision_operator.initialize();
     std::cout << "Initialization time (s): " << std::chrono::duration<double>(clk::now() - t_init).count() << " seconds\n";
 
-    auto evaluate = [&]() {
-        for (int g = 0; g < gpus; ++g) {
-            ops[g]->collidePartial(Q_d[g], f_d[g], g == 0, streams[g]);   // gain_partial + finish_partial, fused
-        }
-        RCCL_OR_DIE(ncclGroupStart());
-        for (int g = 0; g < gpus; ++g)
-            RCCL_OR_DIE(ncclAllReduce(Q_d[g], Q_d[g], G, ncclDouble, ncclSum, comms[g], streams[g]));   // the ONE collective
-        RCCL_OR_DIE(ncclGroupEnd());
-        for (int g = 0; g < gpus; ++g) {
-            HIP_OR_DIE(hipSetDevice(g));
-            HIP_OR_DIE(hipStreamSynchronize(streams[g]));
-        }
-    };
+    auto evaluate = [&]() { collision_operator(Q_d, f_d); };   // blocking
     for (int w = 0; w < warmup; ++w) evaluate();
     std::vector<double> times;
     for (int trial = 0; trial < trials; ++trial) {
@@ -142,8 +112,7 @@ int main(int argc, char** argv) {
     }
     print_stats_summary("HIP x" + std::to_string(gpus), times);
 
-    HIP_OR_DIE(hipSetDevice(gpus - 1));       // every device holds the full answer; check the last one
-    HIP_OR_DIE(hipMemcpy(Q_h.data(), Q_d[gpus - 1], G * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_OR_DIE(hipMemcpy(Q_h.data(), Q_d, G * sizeof(double), hipMemcpyDeviceToHost));
     double err_L1 = 0, err_L2 = 0, err_Linf = 0;
     for (size_t i = 0; i < G; ++i) {
         const double d = std::abs(Q_h[i] - Q_exact[i]);
@@ -157,13 +126,7 @@ int main(int argc, char** argv) {
     std::cout << "{\"backend\": \"HIP\", \"n_gpus\": " << gpus << ", \"Nv\": " << Nv << ", \"Ngl\": " << Ngl << ", \"Ns\": " << Ns
               << ", \"evals_per_s\": " << 1.0 / st.mean << ", \"alg_GBps\": " << (6.0 * B + 9) * G * 16.0 / st.mean / 1e9 << "}\n";
 
-    for (int g = 0; g < gpus; ++g) {
-        HIP_OR_DIE(hipSetDevice(g));
-        ops[g].reset();
-        HIP_OR_DIE(hipFree(f_d[g]));
-        HIP_OR_DIE(hipFree(Q_d[g]));
-        HIP_OR_DIE(hipStreamDestroy(streams[g]));
-        ncclCommDestroy(comms[g]);
-    }
+    HIP_OR_DIE(hipFree(f_d));
+    HIP_OR_DIE(hipFree(Q_d));
     return 0;
 }

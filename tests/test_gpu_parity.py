@@ -413,22 +413,25 @@ def test_n128_fp64_matches_oracle(torch_cuda, oracle):
 
 
 def test_cpp_multi_gpu_driver_on_one_device(torch_cuda):
-    """host/maxwell_bkw_hip_multi.cpp (single process, direction shards, ONE grouped ncclAllReduce on Q) with
-    --gpus 1: RCCL communicator of size 1, same code path as P > 1; cfg3 norms must match the golden values."""
+    """host/maxwell_bkw_hip_multi.cpp = the reference driver with BoltzmannOperator<HIP_MultiGPU_Backend> (single
+    process, f broadcast, direction shards, ONE grouped ncclReduce on Q).  On a one-GPU box: --gpus 1 without
+    collectives, and --force-rccl (communicator of size 1: the broadcast / reduce calls of the P > 1 path are issued);
+    cfg3 norms must match the golden values either way."""
     import re
     import subprocess
     pkg = os.path.join(os.path.dirname(HERE), "boltzmann-fourier-spectral-method_amd")
     exe = os.path.join(pkg, "maxwell_bkw_hip_multi")
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", pkg, "-s", "maxwell_bkw_hip_multi"])
-    out = subprocess.run([exe, "--Nv", "64", "--Ngl", "16", "--Ns", "48", "-t", "3", "--gpus", "1",
-                          "--design-dir", os.path.join(pkg, "data", "sph_design")],
-                         capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0, out.stderr[-2000:]
-    row = [r for r in GOLD["survey"] if r["nv"] == 64][0]
-    got = {k: float(re.search(k + r" error: (\S+)", out.stdout).group(1)) for k in ("L1", "L2", "Linf")}
-    for k in ("L1", "L2", "Linf"):
-        assert got[k] == pytest.approx(row[k], rel=2e-5), (k, got)
+    for extra in ([], ["--force-rccl"], ["--force-rccl", "--hermitian"]):
+        out = subprocess.run([exe, "--Nv", "64", "--Ngl", "16", "--Ns", "48", "-t", "3", "--gpus", "1",
+                              "--design-dir", os.path.join(pkg, "data", "sph_design")] + extra,
+                             capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        row = [r for r in GOLD["survey"] if r["nv"] == 64][0]
+        got = {k: float(re.search(k + r" error: (\S+)", out.stdout).group(1)) for k in ("L1", "L2", "Linf")}
+        for k in ("L1", "L2", "Linf"):
+            assert got[k] == pytest.approx(row[k], rel=2e-5), (k, got, extra)
 
 
 @pytest.mark.parametrize("nv,n_gl,n_sph", [(16, 8, 32), (32, 8, 48), (64, 2, 12)])
