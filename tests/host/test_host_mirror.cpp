@@ -11,6 +11,8 @@
 
 #include "Collisions/AbstractCollisionOperator.hpp"
 #include "Collisions/BoltzmannOperator.hpp"
+#include "Collisions/HIPBoltzmannOperator.hpp"            // declarations only: no HIP / RCCL type may leak into the
+#include "Collisions/HIPMultiGPUBoltzmannOperator.hpp"    // headers a reference driver includes (plain g++ compiles them)
 #include "Quadratures/GaussLegendre.hpp"
 #include "Quadratures/SphericalDesign.hpp"
 #include "Utilities/constants.hpp"
