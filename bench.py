@@ -6,14 +6,21 @@ A "step" is one evaluation Q = Q(f,f) of the Fourier-spectral Boltzmann collisio
 region starts, through the C-ABI of libbfsm_hip.so -- exactly what `collision_operator(Q, f_bkw)` times in the
 reference driver (maxwell_bkw_cuda.cu:144-151).
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (N > 1: starts its own N ranks, see self_launch())
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-         bench.py --gpus N --steps K --warmup W
+         bench.py --gpus N --steps K --warmup W          (the driver's form: RANK / WORLD_SIZE already in the env)
 
 N > 1: the B = M_gl*M_sph quadrature directions are sharded contiguously over the ranks (strong scaling: the
 workload is fixed); each rank computes its partial Q_gain_hat, inverse-transforms it (the transform is linear; rank 0
 also subtracts the loss term) and ONE RCCL all-reduce (torch.distributed "nccl") sums the real Q over xGMI
 (G doubles: half the bytes of summing Q_hat, and no kernel runs after the collective).
+
+What `value` times, for every N: K evaluations issued in order on one stream, evaluation i+1 starting after
+evaluation i -- including its collective -- has finished on the device (what a time stepper that needs Q_i to form
+f_{i+1} sees; no host round trip between evaluations).  Reported beside it, never as `value`:
+  blocking_call : every evaluation followed by a host synchronisation, the reference driver's timing loop
+                  (maxwell_bkw_cuda.cu:144-151; bfsm_collide at N = 1);
+  overlapped    : N > 1 only -- the all-reduce of evaluation i left in flight under the gain kernels of i+1.
 
 Workloads (BASELINE.json configs):  cfg2 N=32,M_gl=8,ss009.048 | cfg3 N=64,M_gl=16,ss009.048 (default, the
 roofline configuration) | cfg4 N=64,M_gl=16,ss017.156 | cfg5 N=128,M_gl=30,ss019.192 fp32.
@@ -105,6 +112,39 @@ def cpu_baseline(w, seconds_target=15.0):
                                    "(Results/maxwell_bkw_fftw_atomics.txt:695), i.e. 0.44 s per cfg3-sized evaluation"}
 
 
+def kernel_source_digest():
+    """sha256 over the kernel sources: ties a PMC traffic profile to the build it was collected on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "boltzmann-fourier-spectral-method_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hpp", ".hip")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILDREN (torch.distributed.run, one process
+    per GPU, rendezvous on 127.0.0.1) before this process has imported torch or touched the GPU, relay rank 0's JSON
+    line (the children inherit stdout) and exit with the launcher's code.  Nothing is exec'ed."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -117,27 +157,46 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-exact", action="store_true", help="skip the extra opt-in exact-reduction measurement")
-    ap.add_argument("--no-overlap", action="store_true",
-                    help="N>1: wait for each evaluation's all-reduce before queueing the next evaluation")
+    ap.add_argument("--no-extras", action="store_true", help="skip the blocking_call / overlapped side measurements")
+    ap.add_argument("--rehearsal", action="store_true",
+                    help="CPU plumbing rehearsal of the N>1 launch path (no GPU, no measurement): the ranks are started, "
+                         "form a gloo group, shard the directions and run the collective with the tests' host emulator "
+                         "of the kernels on a tiny grid; the JSON line carries value = null and rehearsal = true")
     args = ap.parse_args()
 
-    import torch
-    import bfsm
+    if args.gpus < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr)
+        sys.exit(2)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count must equal --gpus",
+                  file=sys.stderr)
         sys.exit(2)
+    if args.rehearsal:
+        return rehearsal(args, world, rank)
+
+    import torch
+    import bfsm
+
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the collision operator has no CPU path", file=sys.stderr)
         sys.exit(3)
     # one rank per GPU.  (Rehearsals on a single-GPU box may set BFSM_BENCH_BACKEND=gloo: the ranks then share
     # device 0 and the collective goes through the host -- same code path, meaningless timings.)
     backend = os.environ.get("BFSM_BENCH_BACKEND", "nccl")
-    dev = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and world > ndev:
+        if rank == 0:
+            print(f"bench.py: --gpus {world} but only {ndev} device(s) visible (BFSM_BENCH_BACKEND=gloo rehearses the "
+                  "N>1 path on fewer devices; its timings mean nothing)", file=sys.stderr)
+        sys.exit(4)
+    dev = local_rank if backend == "nccl" else local_rank % ndev
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
@@ -178,26 +237,31 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def timed(op):
-        """W warm-up + K timed evaluations, barrier + synchronize on both sides, max over ranks."""
+    def timed(op, mode="inorder"):
+        """W warm-up + K timed evaluations, barrier + synchronize on both sides, max over ranks.
+        mode "inorder"  : evaluations queued on one stream, each (with its collective) after the previous one;
+             "blocking" : a host synchronisation after every evaluation (the reference driver's loop);
+             "overlap"  : N>1, two result buffers, the all-reduce of evaluation i in flight under evaluation i+1."""
         qhat = bfsm.device_view(torch, *op.qhatBuffer()) if world > 1 else None
-        # N>1: evaluations are queued back to back exactly as at N=1 (no host wait in between).  Evaluation i+1 does
-        # not read Q_i, so with two result buffers the all-reduce of Q_i (RCCL's stream) runs under the gain kernels
-        # of evaluation i+1; a buffer is waited for before it is written again and before the closing fence.
         Qs = (Q, Q2)
         pending = [None, None]
 
         def step(i):
             s = torch.cuda.current_stream().cuda_stream
             if world == 1:
-                op.computeCollisionAsync(Q, f, s)
-            elif args.no_overlap:
-                bfsm.sharded_step(op, qhat, Q, f, dist, s)   # gain_partial -> finish_partial -> ONE RCCL all-reduce
-            else:
+                if mode == "blocking":
+                    op.computeCollision(Q, f)            # bfsm_collide: returns when the device work has completed
+                else:
+                    op.computeCollisionAsync(Q, f, s)
+            elif mode == "overlap":
                 k = i & 1
                 if pending[k] is not None:
                     pending[k].wait()
                 pending[k] = bfsm.sharded_step(op, qhat, Qs[k], f, dist, s, async_op=True)
+            else:
+                bfsm.sharded_step(op, qhat, Q, f, dist, s)   # gain_partial -> finish_partial -> ONE RCCL all-reduce
+                if mode == "blocking":
+                    torch.cuda.synchronize()
 
         def drain():
             for k in (0, 1):
@@ -236,13 +300,23 @@ def main():
             dist.all_reduce(Q2)
             dist.all_reduce(Q2, async_op=True).wait()
         fence()
-    elapsed = timed(op)
+    elapsed = timed(op, "inorder")
 
     ms_per_step = 1e3 * elapsed / args.steps
     evals_per_s = args.steps / elapsed
     cbytes = 16.0 if prec == 64 else 8.0
     alg_bytes = (6.0 * B + 9.0) * nv ** 3 * cbytes            # whole evaluation, all GPUs
     alg_gbps = alg_bytes / (elapsed / args.steps) / 1e9
+
+    blocking = overlapped = None
+    if not args.no_extras:
+        el = timed(op, "blocking")
+        blocking = {"value": args.steps / el, "unit": "evals/s", "ms_per_step": 1e3 * el / args.steps,
+                    "note": "host synchronisation after every evaluation (maxwell_bkw_cuda.cu:144-151)"}
+        if world > 1:
+            el = timed(op, "overlap")
+            overlapped = {"value": args.steps / el, "unit": "evals/s", "ms_per_step": 1e3 * el / args.steps,
+                          "note": "all-reduce of evaluation i in flight under the gain kernels of evaluation i+1"}
 
     roofline = None
     if not args.no_roofline:
@@ -266,17 +340,24 @@ def main():
         ms, nbytes, launches = acc[dom]
         achieved = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
-        # same command, FETCH doubled per MI355X_MICROARCH.md; profiles/summarize.py).  Only valid for the launch
-        # geometry it was collected on: the default single-GPU cfg3 run.
-        traffic = None
+        # same command, FETCH doubled per MI355X_MICROARCH.md; profiles/summarize.py).  Valid only for the launch
+        # geometry AND the kernel build it was collected on: the profile records workload, precision and a digest of
+        # the kernel sources; anything else reports null (and says why) instead of a stale number.
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath) and world == 1 and args.workload == "cfg3" and prec == 64 and not args.max_chunk:
+        if os.path.exists(tpath) and world == 1 and not args.max_chunk:
             try:
-                traffic = json.load(open(tpath)).get(bfsm.KERNEL_NAMES[dom], {}).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                same_cfg = tj.get("_workload", "cfg3") == args.workload and tj.get("_precision", 64) == prec
+                if same_cfg and tj.get("_kernel_src") == kernel_source_digest():
+                    traffic = tj.get(bfsm.KERNEL_NAMES[dom], {}).get("hbm_bytes_per_launch")
+                    traffic_source = "profiles/" + str(tj.get("_source"))
+                elif same_cfg:
+                    traffic_source = f"profiles/{tj.get('_source')} is older than the kernel sources: not reported"
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "kernel": bfsm.KERNEL_NAMES[dom], "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                     "alg_bytes_per_launch": nbytes / max(launches, 1), "avg_launch_ms": ms / max(launches, 1),
                     "launches_per_eval": launches // reps,
                     "per_kernel": {bfsm.KERNEL_NAMES[i]: {"ms_per_eval": acc[i][0] / reps,
@@ -288,7 +369,7 @@ def main():
     exact = None
     if not args.no_exact:
         ope = make(False, exact=True)
-        el = timed(ope)
+        el = timed(ope, "inorder")
         cn = ope.counters()
         exact = {"value": args.steps / el, "unit": "evals/s", "ms_per_step": 1e3 * el / args.steps,
                  "moved_bytes_per_eval_model": cn.moved_bytes_per_eval * world if world == 1 else None,
@@ -305,6 +386,11 @@ def main():
 
     op.destroy()
     if rank == 0:
+        collective = None
+        if world > 1:
+            collective = {"backend": dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else ""),
+                          "ranks": dist.get_world_size(), "per_evaluation": "1 all-reduce (sum) of Q: "
+                          f"{nv ** 3 * 8} bytes per rank", "devices_visible": ndev}
         out = {
             "metric": "collision-operator evals/sec", "value": evals_per_s, "unit": "evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -313,15 +399,61 @@ def main():
             "config": {"workload": f"{args.workload}: N={nv}^3 grid, M_gl={n_gl}, {w['design']} ({n_sph} pts), "
                                    f"B={B} directions, BKW f (t=6.5), Maxwell molecules",
                        "directions_per_gpu": B // world, "parallelism": f"direction-shard x{world} + 1 all-reduce",
-                       "collective_overlap": bool(world > 1 and not args.no_overlap)},
+                       "timing": "in-order: evaluation i+1 starts after evaluation i and its collective have finished",
+                       "collective_overlap": False, "collective": collective},
             "achieved_alg_GBps": alg_gbps, "frac_of_hbm_peak": alg_gbps / (HBM_PEAK_GBPS * world),
             "frac_of_measured_copy_ceiling": alg_gbps / (HBM_COPY_CEILING_GBPS * world),
             "alg_bytes_per_eval": alg_bytes,
-            "roofline": roofline, "cpu_baseline": cpu, "exact_reductions": exact,
+            "roofline": roofline, "cpu_baseline": cpu, "blocking_call": blocking, "overlapped": overlapped,
+            "exact_reductions": exact,
         }
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def rehearsal(args, world, rank):
+    """--rehearsal: the N>1 launch / shard / collective plumbing on CPU (gloo), the tests' host emulator of the kernel
+    bodies standing in for the device.  Not a measurement: value and ms_per_step are null."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import bfsm
+    import emu_lib as E
+    from bfsm import quadrature as Qd
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    nv, n_gl, n_sph = 16, 2, 12
+    c = bfsm.reference_constants()
+    f_h = bfsm.bkw_solution(nv)[0]
+    glq, spq = bfsm.GaussLegendreQuadrature(n_gl, 0.0, c["R"]), bfsm.SphericalDesign(n_sph)
+    gl = (np.asarray(glq.getNodes()), np.asarray(glq.getWeights()))
+    sph = (np.asarray(spq.getx()), np.asarray(spq.gety()), np.asarray(spq.getz()), np.asarray(spq.getWeights()))
+    shard = bfsm.shard_range(n_gl * n_sph, rank, world)
+    op = E.EmuOperatorFused(nv, gl, sph, c["gamma"], c["b_gamma"], c["L"], dir_range=shard)
+    f = torch.from_numpy(f_h.reshape(-1).copy())
+    Q = torch.empty_like(f)
+    for _ in range(args.warmup + args.steps):
+        bfsm.sharded_step(op, op.qhat, Q, f, dist if world > 1 else None)
+    whole = E.EmuOperatorFused(nv, gl, sph, c["gamma"], c["b_gamma"], c["L"])
+    Qw = torch.empty_like(f)
+    bfsm.sharded_step(whole, whole.qhat, Qw, f, None)
+    err = float((Q - Qw).abs().max() / Qw.abs().max())
+    if rank == 0:
+        print(json.dumps({"metric": "collision-operator evals/sec", "value": None, "unit": "evals/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+                          "scaling": "strong", "vs_baseline": None, "dtype": "f64", "rehearsal": True,
+                          "data": "REHEARSAL on CPU: host emulator of the kernels, gloo; not a measurement",
+                          "config": {"workload": f"rehearsal: N={nv}, M_gl={n_gl}, {n_sph}-point design",
+                                     "collective": {"backend": "gloo", "ranks": dist.get_world_size() if world > 1 else 1}},
+                          "sharded_vs_whole_rel_err": err}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    if not err <= 1e-13:
+        sys.exit(5)
 
 
 if __name__ == "__main__":

@@ -203,6 +203,7 @@ struct HipBackend {
         void* p = nullptr;
         hipError_t e = hipMalloc(&p, bytes);
         note(e, "hipMalloc", __LINE__);
+        if (e != hipSuccess) (void)hipGetLastError();   // reported through the status code: do not leave it sticky
         return e == hipSuccess ? p : nullptr;
     }
     void release(void* p) { BFSM_NOTE(hipFree(p)); }
@@ -235,8 +236,11 @@ struct HipBackend {
         Rec rec{pend_kind, pend_bytes, nullptr, nullptr};
         const bool timed = profile && pend_kind >= 0;
         if (timed) { rec.e0 = next_event(); rec.e1 = next_event(); BFSM_NOTE(hipEventRecord(rec.e0, stream)); }
-        hipLaunchKernelGGL(fn, dim3((unsigned)gx, (unsigned)gy, (unsigned)gz), dim3(threads, 1, 1), lds, stream, prm);
-        BFSM_NOTE(hipGetLastError());
+        // hipLaunchKernel returns this launch's own status: an earlier, unrelated sticky error of the calling thread
+        // (a failed hipMalloc of another handle, the caller's own HIP calls) is neither blamed on it nor consumed
+        void* args[] = {const_cast<void*>(static_cast<const void*>(&prm))};
+        BFSM_NOTE(hipLaunchKernel(reinterpret_cast<const void*>(fn), dim3((unsigned)gx, (unsigned)gy, (unsigned)gz),
+                                  dim3(threads, 1, 1), args, lds, stream));
         if (timed) { BFSM_NOTE(hipEventRecord(rec.e1, stream)); recs.push_back(rec); }
         pend_kind = -1;
     }
@@ -271,6 +275,7 @@ struct bfsm_plan {
     std::string err;
     bfsm_counters counters{};
     bool full_shard = true;
+    std::vector<hipStream_t> pending;   // streams this handle has enqueued on since its last bfsm_synchronize
 };
 
 static thread_local std::string g_create_error;
@@ -381,6 +386,15 @@ int bfsm_create(const bfsm_desc* desc, bfsm_handle* out) {
 static int enter(bfsm_plan* h, const DeviceGuard& g, void* stream) {
     if (g.err != hipSuccess) return fail(h, BFSM_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(g.err));
     h->be.stream = (hipStream_t)stream;
+    bool seen = false;
+    for (hipStream_t s : h->pending) seen = seen || s == h->be.stream;
+    if (!seen) {
+        if (h->pending.size() >= 16) {      // bounded: retire the oldest stream before remembering another one
+            (void)hipStreamSynchronize(h->pending.front());
+            h->pending.erase(h->pending.begin());
+        }
+        h->pending.push_back(h->be.stream);
+    }
     return BFSM_OK;
 }
 
@@ -478,8 +492,10 @@ int bfsm_synchronize(bfsm_handle h) {
     BFSM_GUARDED(h,
         DeviceGuard g(h->desc.device);
         hipError_t e = g.err;
-        if (e == hipSuccess) e = hipStreamSynchronize(h->be.stream);
+        for (hipStream_t s : h->pending)    // every stream a call on this handle was given, not only the last one
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) return fail(h, BFSM_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+        h->pending.clear();
         return BFSM_OK;
     )
 }

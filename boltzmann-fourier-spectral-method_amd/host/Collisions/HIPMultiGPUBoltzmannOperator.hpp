@@ -12,6 +12,9 @@
 // device evaluates its contiguous shard of the M_gl * M_sph quadrature directions and inverse-transforms its own partial
 // sum (bfsm_collide_partial_async; the first device also subtracts the loss term), and ONE grouped RCCL reduce over
 // xGMI sums the real Q into the caller's buffer.  With one device no RCCL call is made.
+// Each device is driven by its own host thread (created by initialize()), so the devices' launch sequences and their
+// two RCCL calls are issued concurrently; the calling thread only publishes (Q, f) and waits.  f must be complete, or
+// enqueued on the first device's default stream (what the reference's driver does), when the call is made.
 // No HIP or RCCL type appears in this header; the implementation is host/HIPMultiGPUBoltzmannOperator.cpp.
 #pragma once
 #include <memory>

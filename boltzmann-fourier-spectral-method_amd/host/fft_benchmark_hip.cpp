@@ -114,7 +114,7 @@ int main(int argc, char** argv) {
     std::cout << "L1 error: " << l1 << "\n";
     print_stats_summary("HIP tile + line passes", times);
     const double best = *std::min_element(times.begin(), times.end());
-    std::cout << "Batch of " << batch_size << " transforms, " << (4.0 * grid_size * elem * batch_size) / 1e9
+    std::cout << std::defaultfloat << std::setprecision(6) << "Batch of " << batch_size << " transforms, " << (4.0 * grid_size * elem * batch_size) / 1e9
               << " GB over the two passes: " << (4.0 * grid_size * elem * batch_size) / best / 1e12 << " TB/s (best trial)\n";
 
     HIP_OR_DIE(hipFree(f));

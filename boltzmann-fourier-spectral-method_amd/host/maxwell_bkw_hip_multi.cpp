@@ -123,7 +123,7 @@ int main(int argc, char** argv) {
     std::cout << "Approximation errors:\nL1 error: " << err_L1 * dv * dv * dv << "\nL2 error: " << std::sqrt(err_L2 * dv * dv * dv)
               << "\nLinf error: " << err_Linf << "\n\n";
     const RunStats st = summarize(times);
-    std::cout << "{\"backend\": \"HIP\", \"n_gpus\": " << gpus << ", \"Nv\": " << Nv << ", \"Ngl\": " << Ngl << ", \"Ns\": " << Ns
+    std::cout << std::defaultfloat << std::setprecision(6) << "{\"backend\": \"HIP\", \"n_gpus\": " << gpus << ", \"Nv\": " << Nv << ", \"Ngl\": " << Ngl << ", \"Ns\": " << Ns
               << ", \"evals_per_s\": " << 1.0 / st.mean << ", \"alg_GBps\": " << (6.0 * B + 9) * G * 16.0 / st.mean / 1e9 << "}\n";
 
     HIP_OR_DIE(hipFree(f_d));

@@ -72,8 +72,8 @@ typedef struct bfsm_plan* bfsm_handle;
  * Quadratures/AbstractSphericalQuadratures.hpp:21-42).  All arrays are HOST pointers, copied during create.
  */
 typedef struct bfsm_desc {
-    int nvx, nvy, nvz;        /* velocity grid; this build has kernels for nvx == nvy == nvz in {16,32,64,128}
-                                 (128 only with BFSM_F32) */
+    int nvx, nvy, nvz;        /* velocity grid; this build has kernels for nvx == nvy == nvz in {16,32,64,128},
+                                 in both precisions */
     int n_gl;                 /* Gauss-Legendre points (radial)          */
     int n_sph;                /* spherical quadrature points             */
     const double* gl_nodes;   /* [n_gl]  rho_r on [0,R]                   */
@@ -121,8 +121,8 @@ int bfsm_create(const bfsm_desc* desc, bfsm_handle* out);
  * Requires a handle that owns ALL directions (dir_begin,dir_end = 0,0 or 0,n_gl*n_sph). */
 int bfsm_collide(bfsm_handle h, double* Q_dev, const double* f_dev);
 
-/* Same, enqueued on `stream` (a hipStream_t cast to void*; NULL = the handle's own stream) without the final
- * host synchronisation. */
+/* Same, enqueued on `stream` (a hipStream_t cast to void*; NULL = the device's legacy default stream, which is what
+ * the reference launches on, cu:131-218) without the final host synchronisation. */
 int bfsm_collide_async(bfsm_handle h, double* Q_dev, const double* f_dev, void* stream);
 
 /* Batch of distributions (new functionality): f_dev and Q_dev hold n_batch <= desc.max_batch
@@ -157,7 +157,8 @@ int bfsm_collide_partial_async(bfsm_handle h, double* Q_dev, const double* f_dev
  * library's spectral layout [lx][lz][ly]); the buffer the collective must sum in place. */
 void* bfsm_qhat_buffer(bfsm_handle h, size_t* n_elems, int* precision);
 
-/* Blocks until everything enqueued by this handle has completed. */
+/* Blocks until everything enqueued by this handle has completed: every stream that was passed to one of its entry
+ * points since the previous bfsm_synchronize is waited for, not only the most recent one. */
 int bfsm_synchronize(bfsm_handle h);
 
 /* Batched 3-D complex transform with the library's own kernels (counterpart of the cufftPlanMany plan,

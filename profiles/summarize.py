@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turn rocprofv3 output directories (gpurun_out/prof_*) into the small summaries committed under profiles/.
 
-usage: summarize.py TAG STATS_DIR FETCH_DIR WRITE_DIR NOTE
+usage: summarize.py TAG STATS_DIR FETCH_DIR WRITE_DIR NOTE [WORKLOAD [PRECISION]]
   STATS_DIR : rocprofv3 --kernel-trace --stats --output-format csv  -- python3 bench.py ...
   FETCH_DIR : rocprofv3 --pmc FETCH_SIZE --output-format csv        -- python3 bench.py ...   (own pass)
   WRITE_DIR : rocprofv3 --pmc WRITE_SIZE --output-format csv        -- python3 bench.py ...   (own pass)
@@ -30,6 +30,8 @@ def kind_of(name):
 
 def main():
     tag, stats_dir, fetch_dir, write_dir, note = sys.argv[1:6]
+    workload = sys.argv[6] if len(sys.argv) > 6 else "cfg3"
+    precision = int(sys.argv[7]) if len(sys.argv) > 7 else (32 if workload == "cfg5" else 64)
     here = os.path.dirname(os.path.abspath(__file__))
     stats = glob.glob(os.path.join(stats_dir, "**", "*kernel_stats.csv"), recursive=True)[0]
     shutil.copy(stats, os.path.join(here, f"{tag}_kernel_stats.csv"))
@@ -57,7 +59,14 @@ def main():
     json.dump(out, open(os.path.join(here, f"{tag}_pmc_traffic.json"), "w"), indent=1, sort_keys=True)
     latest = {g: {"hbm_bytes_per_launch": out[k]["hbm_bytes_per_launch"]} for g, k in GROUP.items() if k in out}
     latest["_source"] = f"{tag}_pmc_traffic.json"
-    json.dump(latest, open(os.path.join(here, "traffic_latest.json"), "w"), indent=1, sort_keys=True)
+    # bench.py reports this traffic only for the workload and the kernel build it was collected on
+    latest["_workload"], latest["_precision"] = workload, precision
+    sys.path.insert(0, os.path.dirname(here))
+    import bench
+    latest["_kernel_src"] = out["_kernel_src"] = bench.kernel_source_digest()
+    json.dump(out, open(os.path.join(here, f"{tag}_pmc_traffic.json"), "w"), indent=1, sort_keys=True)
+    if workload == "cfg3":      # the default bench command is the one whose roofline object quotes the traffic
+        json.dump(latest, open(os.path.join(here, "traffic_latest.json"), "w"), indent=1, sort_keys=True)
     for k in ("gain_inv", "gain_line", "gain_fwd", "reduce"):
         if k in out:
             print(k, {a: round(b, 1) for a, b in out[k].items()})

@@ -27,6 +27,23 @@ def test_bench_rejects_a_world_size_mismatch():
     assert out.returncode == 2 and "WORLD_SIZE" in out.stderr
 
 
+def test_bench_gpus_2_launches_its_own_ranks_cpu_rehearsal():
+    """`python bench.py --gpus 2` invoked directly, with no launcher and no WORLD_SIZE: bench.py must start its own two
+    ranks (children, before anything touches a GPU) and rank 0 must print exactly one JSON line with n_gpus = 2.  On
+    CPU this is the --rehearsal mode (gloo, the host emulator of the kernels): plumbing only, value = null."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--rehearsal"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["rehearsal"] is True and d["value"] is None and d["ms_per_step"] is None      # never a measurement
+    assert d["config"]["collective"] == {"backend": "gloo", "ranks": 2}
+    assert d["sharded_vs_whole_rel_err"] <= 1e-13
+
+
 @pytest.mark.gpu
 def test_bench_prints_one_json_line_with_the_contract_keys():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1"],
@@ -52,3 +69,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
         assert k in c, k
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
     assert d["value"] > 50 * c["value"]          # sanity: the GPU path is not the CPU path
+    # the reference driver's blocking loop beside the headline; the PMC traffic only when its profile matches the build
+    assert 0 < d["blocking_call"]["value"] <= d["value"] * 1.02 and d["overlapped"] is None
+    assert d["config"]["collective"] is None and d["config"]["collective_overlap"] is False
+    assert (r["traffic"] is None) or (r["traffic_source"].startswith("profiles/") and r["traffic"] > 0)

@@ -1,6 +1,7 @@
 """-m gpu: parity of the HIP path (through the C-ABI) against the oracle, the golden BKW norms, and
 size-independent properties at BASELINE.json's full sizes.  Tolerances (fp64): max|Q - Q_ref| <= 1e-12 max|Q_ref|
-(BASELINE.md section 3), |L2err - L2err_ref| <= 1e-10 (north star).  fp32 variant: 1e-4 relative."""
+(BASELINE.md section 3), |L2err - L2err_ref| <= 1e-10 (north star).  fp32 variant: 5e-6 relative (measured: 1.1e-6 on
+the full config 5 quadrature)."""
 import json
 import os
 
@@ -12,7 +13,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD = json.load(open(os.path.join(HERE, "golden", "bkw_norms.json")))
 TOL64 = 1e-12
-TOL32 = 1e-4
+TOL32 = 5e-6
 
 
 @pytest.fixture(scope="module")
@@ -247,7 +248,8 @@ def test_cpp_driver_reproduces_published_norms(torch_cuda):
         got = {k: float(re.search(k + r" error: (\S+)", text).group(1)) for k in ("L1", "L2", "Linf")}
         row = GOLD["published"][0]
         for k in ("L1", "L2", "Linf"):
-            assert got[k] == pytest.approx(row[k], rel=2e-5), (k, got, text)     # std::cout prints 6 significant digits
+            # the stream is left in scientific / precision 8 like the reference's: the log line IS the archived line
+            assert re.search(k + r" error: (\S+)", text).group(1) == "%.8e" % row[k], (k, got, text)
 
 
 @pytest.mark.parametrize("nv,n_gl,n_sph", [(16, 8, 32), (32, 8, 48), (64, 2, 12)])
@@ -431,7 +433,8 @@ def test_cpp_multi_gpu_driver_on_one_device(torch_cuda):
         row = [r for r in GOLD["survey"] if r["nv"] == 64][0]
         got = {k: float(re.search(k + r" error: (\S+)", out.stdout).group(1)) for k in ("L1", "L2", "Linf")}
         for k in ("L1", "L2", "Linf"):
-            assert got[k] == pytest.approx(row[k], rel=2e-5), (k, got, extra)
+            assert got[k] == pytest.approx(row[k], rel=6e-9), (k, got, extra)     # 9 printed digits
+            assert re.fullmatch(r"\d\.\d{8}e[-+]\d\d", re.search(k + r" error: (\S+)", out.stdout).group(1))
 
 
 @pytest.mark.parametrize("nv,n_gl,n_sph", [(16, 8, 32), (32, 8, 48), (64, 2, 12)])
@@ -462,23 +465,113 @@ def test_hermitian_full_size(torch_cuda, oracle):
 
 
 def test_bench_two_ranks_rehearsal(torch_cuda):
-    """bench.py under torch.distributed.run with 2 ranks.  A one-GPU box cannot host two RCCL ranks, so the
-    rehearsal backend (gloo, both ranks on device 0) is used: same sharding, same bfsm.sharded_step, same timing and
-    JSON code path as the 8-GPU run; only the collective's transport differs."""
+    """`python bench.py --gpus 2` invoked DIRECTLY (no launcher): bench.py starts its own two ranks.  A one-GPU box
+    cannot host two RCCL ranks, so the rehearsal backend (gloo, both ranks on device 0) is used: same self-launch, same
+    sharding, same bfsm.sharded_step on the HIP operator, same timing and JSON code path as the 8-GPU run; only the
+    collective's transport differs."""
     import subprocess
     import sys
     root = os.path.dirname(HERE)
-    env = dict(os.environ, BFSM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(BFSM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"),
                           "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "cfg2", "--no-roofline"],
                          capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert out.returncode == 0, out.stderr[-3000:]
-    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
-    d = json.loads(line)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "strong"
     assert d["config"]["directions_per_gpu"] == 192 and d["cpu_baseline"] is None
+    assert d["config"]["collective"]["ranks"] == 2 and d["config"]["collective_overlap"] is False
+    assert d["blocking_call"]["value"] > 0 and d["overlapped"]["value"] > 0
     assert d["exact_reductions"]["value"] > 0
+
+
+def test_bench_refuses_more_ranks_than_devices(torch_cuda):
+    """With the RCCL backend every rank needs its own GPU: asking for more is an error (rc 4), not a silent sharing."""
+    import subprocess
+    import sys
+    import torch
+    root = os.path.dirname(HERE)
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BFSM_BENCH_BACKEND")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode != 0 and "device(s) visible" in out.stderr
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_two_real_gpus_when_present(torch_cuda, oracle):
+    """On a box with >= 2 GPUs (the development box has one: skipped there): the single-process multi-GPU operator
+    (maxwell_bkw_hip_multi --gpus 2: ncclCommInitAll, broadcast, per-device threads, ncclReduce) reproduces the cfg3
+    golden norms, and bench.py --gpus 2 over RCCL prints its line."""
+    import re
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    root = os.path.dirname(HERE)
+    pkg = os.path.join(root, "boltzmann-fourier-spectral-method_amd")
+    out = subprocess.run([os.path.join(pkg, "maxwell_bkw_hip_multi"), "--Nv", "64", "--Ngl", "16", "--Ns", "48", "-t", "3",
+                          "--gpus", "2", "--design-dir", os.path.join(pkg, "data", "sph_design")],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    row = [r for r in GOLD["survey"] if r["nv"] == 64][0]
+    for k in ("L1", "L2", "Linf"):
+        assert float(re.search(k + r" error: (\S+)", out.stdout).group(1)) == pytest.approx(row[k], rel=6e-9)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BFSM_BENCH_BACKEND")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["config"]["collective"]["ranks"] == 2 and "nccl" in d["config"]["collective"]["backend"]
+
+
+_FULL_REF = {}
+
+
+def _full_ref(oracle, nv, n_gl, n_sph):
+    """Oracle field on the perturbed (non-symmetric, Nyquist-populated) input, computed once per configuration."""
+    import bfsm
+    key = (nv, n_gl, n_sph)
+    if key not in _FULL_REF:
+        f_h = bfsm.perturbed_input(bfsm.bkw_solution(nv)[0])
+        _FULL_REF[key] = (f_h, _oracle(oracle, f_h, n_gl, n_sph))
+    return _FULL_REF[key]
+
+
+@pytest.mark.parametrize("mode", ["faithful", "exact", "hermitian"])
+@pytest.mark.parametrize("nv,n_gl,n_sph", [(64, 16, 48), (64, 16, 156), (128, 2, 48)],
+                         ids=["cfg3", "cfg4", "N128_2x48"])
+def test_full_size_field_matches_oracle(torch_cuda, oracle, nv, n_gl, n_sph, mode):
+    """The whole fp64 field at BASELINE.json's config 3 and config 4 sizes (and N = 128 with 96 directions) against the
+    oracle on an input without any symmetry: max|Q - Q_oracle| <= 1e-12 max|Q_oracle|, in all three modes (the
+    isotropic BKW norms cannot see a symmetry shortcut; this can)."""
+    import bfsm
+    f_h, ref = _full_ref(oracle, nv, n_gl, n_sph)
+    op = _make(bfsm, nv, n_gl, n_sph, 64, exact=(mode != "faithful"), hermitian=(mode == "hermitian"))
+    got = _collide(torch_cuda, op, f_h)
+    op.destroy()
+    assert np.abs(got - ref).max() <= TOL64 * np.abs(ref).max()
+
+
+def test_failed_create_does_not_poison_the_next_handle(torch_cuda):
+    """A create that fails with BFSM_ERR_NOMEM (scratch for an absurd batch) must not leave a sticky HIP error behind
+    that the next, healthy handle's first launch would be blamed for: the documented recovery is to retry smaller."""
+    import bfsm
+    from bfsm import capi
+    torch = torch_cuda
+    with pytest.raises(bfsm.BfsmError) as e:
+        _make(bfsm, 64, 16, 48, max_batch=400)           # 2 x 400 x 768 x 4 MiB of A1'/A2' scratch: 2.4 TB
+    assert e.value.code == 4                              # BFSM_ERR_NOMEM
+    op = _make(bfsm, 16, 2, 6)
+    f = torch.from_numpy(bfsm.bkw_solution(16)[0]).cuda()
+    Q = torch.empty_like(f)
+    op(Q, f)                                              # raises on any non-zero status
+    assert torch.isfinite(Q).all()
+    op.destroy()
 
 
 def test_cpp_relaxation_driver(torch_cuda):

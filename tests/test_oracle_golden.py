@@ -37,7 +37,7 @@ def test_published_norms_n32(oracle, row):
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize("row", [r for r in GOLD["published"] if r["nv"] == 64 and r["n_sph"] == 12], ids=lambda r: f"N{r['nv']}_gl{r['n_gl']}_s{r['n_sph']}")
+@pytest.mark.parametrize("row", [r for r in GOLD["published"] if r["nv"] == 64], ids=lambda r: f"N{r['nv']}_gl{r['n_gl']}_s{r['n_sph']}")
 def test_published_norms_n64(oracle, row):
     _, norms = _run(oracle, row)
     _check(row, norms)
@@ -52,6 +52,33 @@ def test_survey_recorded_values(oracle, row):
     if "probe" in row:
         i, j, k, v = row["probe"]
         assert Q[i, j, k] == pytest.approx(v, rel=2e-12)
+
+
+def test_axis_permutation_equivariance(oracle):
+    """Permuting the velocity axes of f together with the components of the quadrature directions permutes Q exactly
+    (up to rounding): pins the anisotropic wiring -- which sigma component multiplies which mode index, the layout of
+    the 3-D transforms -- that the isotropic BKW norms cannot see.  Also: the order of the directions is immaterial."""
+    f, _, L, _ = oracle.bkw(16)
+    f = oracle.perturbed_input(f)                      # no symmetry, energy in every Nyquist plane
+    gl = oracle.gauss_legendre(3, 0.0, R)
+    x, y, z, w = oracle.spherical_design(12)
+    # rotate the design first so that no axis permutation maps it onto itself
+    a, b = 0.3, 1.1
+    x, y = np.cos(a) * x - np.sin(a) * y, np.sin(a) * x + np.cos(a) * y
+    y, z = np.cos(b) * y - np.sin(b) * z, np.sin(b) * y + np.cos(b) * z
+    sig = np.stack([x, y, z])
+    q0 = oracle.collide(f, gl, (x, y, z, w), GAMMA, B_GAMMA, L)
+    for perm in ((1, 2, 0), (2, 0, 1), (1, 0, 2), (0, 2, 1), (2, 1, 0)):
+        fp = np.ascontiguousarray(f.transpose(perm))               # fp[i0,i1,i2] = f at velocity axes permuted
+        sp = sig[list(perm)]
+        qp = oracle.collide(fp, gl, (sp[0].copy(), sp[1].copy(), sp[2].copy(), w), GAMMA, B_GAMMA, L)
+        assert np.abs(qp - q0.transpose(perm)).max() <= 1e-13 * np.abs(q0).max(), perm
+        # the wrong pairing must be visibly different (the check has teeth)
+        qbad = oracle.collide(fp, gl, (x, y, z, w), GAMMA, B_GAMMA, L)
+        assert np.abs(qbad - q0.transpose(perm)).max() >= 1e-6 * np.abs(q0).max(), perm
+    order = np.random.default_rng(3).permutation(12)
+    qs = oracle.collide(f, gl, (x[order].copy(), y[order].copy(), z[order].copy(), w[order].copy()), GAMMA, B_GAMMA, L)
+    assert np.abs(qs - q0).max() <= 1e-13 * np.abs(q0).max()
 
 
 def test_c_oracle_matches_numpy_restatement(oracle):
