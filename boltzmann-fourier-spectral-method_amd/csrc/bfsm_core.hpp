@@ -172,9 +172,26 @@ struct Twiddles {
     }
 };
 
-template <int N, int NP, int SGN, typename T, bool SPLIT = false, class Ctx>
+// LDS exchange discipline.  Every exchange is  [barrier] -> write -> barrier -> read -> [barrier].  Between the reads
+// of one exchange and the writes of the next there must be exactly one barrier; where it sits is a scheduling choice:
+//   SYNC_POST (behind the reads): a wave that finishes the butterflies between two exchanges stores its results at once,
+//             while the slower waves of its SIMD still compute, so the LDS stores (the slow side of the LDS, ~80 B/clk
+//             against 256 B/clk for reads) overlap the other waves' arithmetic instead of starting together;
+//   SYNC_PRE  (in front of the writes): nothing waits behind the reads, so global loads / stores that follow the last
+//             exchange of a tile are issued without a rendezvous.
+// fft_tile uses POST inside the tile and leaves the last exchange open (the next tile's first exchange has PRE).
+// BFSM_SYNC_BEFORE_WRITE restores PRE everywhere (the round-1 placement).
+enum : int { SYNC_PRE = 1, SYNC_POST = 2 };
+#ifdef BFSM_SYNC_BEFORE_WRITE
+#define BFSM_SYNC_FIX(x) (SYNC_PRE)
+#else
+#define BFSM_SYNC_FIX(x) (x)
+#endif
+
+template <int N, int NP, int SGN, typename T, bool SPLIT = false, int SYNC_ = SYNC_PRE, class Ctx>
 BFSM_HD void fft_line_np(cx<T>* v, cx<T>* lds, int p, int u, const Twiddles<N, T>& twr, Ctx& ctx) {
     constexpr int E = Wg<N>::E, TT = Wg<N>::T, Q = Wg<N>::Q, LS = NP + 1;   // p in [0, NP): LDS column
+    constexpr int SYNC = BFSM_SYNC_FIX(SYNC_);
     SmallDft<E, SGN, T>::run(v);
 #pragma unroll
     for (int k1 = 1; k1 < E; ++k1) {
@@ -183,24 +200,25 @@ BFSM_HD void fft_line_np(cx<T>* v, cx<T>* lds, int p, int u, const Twiddles<N, T
     }
     cx<T> w2[E];
     if constexpr (!SPLIT) {
-        ctx.sync();  // previous readers of lds are done
+        if constexpr ((SYNC & SYNC_PRE) != 0) ctx.sync();
 #pragma unroll
-        for (int k1 = 0; k1 < E; ++k1) lds[(k1 * TT + u) * LS + p] = v[k1];
+        for (int k1 = 0; k1 < E; ++k1) ctx.lds_st(lds + (k1 * TT + u) * LS + p, v[k1]);
         ctx.sync();
 #pragma unroll
         for (int q = 0; q < Q; ++q)
 #pragma unroll
-            for (int uu = 0; uu < TT; ++uu) w2[q * TT + uu] = lds[((u + TT * q) * TT + uu) * LS + p];
+            for (int uu = 0; uu < TT; ++uu) w2[q * TT + uu] = ctx.lds_ld(lds + ((u + TT * q) * TT + uu) * LS + p);
+        if constexpr ((SYNC & SYNC_POST) != 0) ctx.sync();
     } else {   // real parts, then imaginary parts, through a scalar buffer (see split_tile)
         T* ls = reinterpret_cast<T*>(lds);
-        ctx.sync();
+        if constexpr ((SYNC & SYNC_PRE) != 0) ctx.sync();
 #pragma unroll
         for (int k1 = 0; k1 < E; ++k1) ls[(k1 * TT + u) * LS + p] = v[k1].x;
         ctx.sync();
 #pragma unroll
         for (int q = 0; q < Q; ++q)
 #pragma unroll
-            for (int uu = 0; uu < TT; ++uu) w2[q * TT + uu].x = ls[((u + TT * q) * TT + uu) * LS + p];
+            for (int uu = 0; uu < TT; ++uu) w2[q * TT + uu].x = ctx.lds_ld_s(ls + ((u + TT * q) * TT + uu) * LS + p);
         ctx.sync();
 #pragma unroll
         for (int k1 = 0; k1 < E; ++k1) ls[(k1 * TT + u) * LS + p] = v[k1].y;
@@ -208,7 +226,8 @@ BFSM_HD void fft_line_np(cx<T>* v, cx<T>* lds, int p, int u, const Twiddles<N, T
 #pragma unroll
         for (int q = 0; q < Q; ++q)
 #pragma unroll
-            for (int uu = 0; uu < TT; ++uu) w2[q * TT + uu].y = ls[((u + TT * q) * TT + uu) * LS + p];
+            for (int uu = 0; uu < TT; ++uu) w2[q * TT + uu].y = ctx.lds_ld_s(ls + ((u + TT * q) * TT + uu) * LS + p);
+        if constexpr ((SYNC & SYNC_POST) != 0) ctx.sync();
     }
 #pragma unroll
     for (int q = 0; q < Q; ++q) SmallDft<TT, SGN, T>::run(w2 + q * TT);
@@ -219,41 +238,48 @@ BFSM_HD void fft_line_np(cx<T>* v, cx<T>* lds, int p, int u, const Twiddles<N, T
         for (int k2 = 0; k2 < TT; ++k2) v[q + Q * k2] = w2[q * TT + k2];
 }
 
-template <int N, int SGN, typename T, class Ctx>
+template <int N, int SGN, typename T, int SYNC_ = SYNC_PRE, class Ctx>
 BFSM_HD void fft_line(cx<T>* v, cx<T>* lds, int p, int u, const Twiddles<N, T>& twr, Ctx& ctx) {
-    fft_line_np<N, N, SGN, T, split_tile<N, T>()>(v, lds, p, u, twr, ctx);
+    fft_line_np<N, N, SGN, T, split_tile<N, T>(), SYNC_>(v, lds, p, u, twr, ctx);
 }
 
 // ---- 2-D transform of an N x N tile with transposition -------------------------------------------------------
 // entry: v[m] = tile[a = u + T*m][c = p]      (c is the contiguous axis of the source)
 // exit : v[m] = TILE[a' = p][c' = u + T*m]    (to be stored as out[c'][a'], a' contiguous)
-template <int N, int SGN, typename T, class Ctx>
+// LAST_POST: close the last exchange with a barrier behind its reads (pays when arithmetic or stores follow: KA) or leave
+// it open for the next tile's first exchange (pays when the next tile's global loads follow: KC at two workgroups per CU).
+template <int N, int SGN, typename T, bool LAST_POST = false, class Ctx>
 BFSM_HD void fft_tile(cx<T>* v, cx<T>* lds, int p, int u, const Twiddles<N, T>& twr, Ctx& ctx) {
     constexpr int E = Wg<N>::E, TT = Wg<N>::T, LS = Wg<N>::LS;
-    fft_line<N, SGN, T>(v, lds, p, u, twr, ctx);  // along a
+    // the split-exchange geometry keeps the round-1 placement (measured: the new one is slower there)
+    constexpr bool OLD = split_tile<N, T>();
+    constexpr int SYNC = OLD ? SYNC_PRE : BFSM_SYNC_FIX(SYNC_POST);   // the transposing exchange
+    fft_line<N, SGN, T, OLD ? SYNC_PRE : (SYNC_PRE | SYNC_POST)>(v, lds, p, u, twr, ctx);  // along a
     if constexpr (!split_tile<N, T>()) {
+        if constexpr ((SYNC & SYNC_PRE) != 0) ctx.sync();
+#pragma unroll
+        for (int m = 0; m < E; ++m) ctx.lds_st(lds + (u + TT * m) * LS + p, v[m]);  // row a', column c
         ctx.sync();
 #pragma unroll
-        for (int m = 0; m < E; ++m) lds[(u + TT * m) * LS + p] = v[m];  // row a', column c
-        ctx.sync();
-#pragma unroll
-        for (int m = 0; m < E; ++m) v[m] = lds[p * LS + (u + TT * m)];  // lane = a', own c = u + T*m
+        for (int m = 0; m < E; ++m) v[m] = ctx.lds_ld(lds + p * LS + (u + TT * m));  // lane = a', own c = u + T*m
+        if constexpr ((SYNC & SYNC_POST) != 0) ctx.sync();
     } else {
         T* ls = reinterpret_cast<T*>(lds);
-        ctx.sync();
+        if constexpr ((SYNC & SYNC_PRE) != 0) ctx.sync();
 #pragma unroll
         for (int m = 0; m < E; ++m) ls[(u + TT * m) * LS + p] = v[m].x;
         ctx.sync();
 #pragma unroll
-        for (int m = 0; m < E; ++m) v[m].x = ls[p * LS + (u + TT * m)];
+        for (int m = 0; m < E; ++m) v[m].x = ctx.lds_ld_s(ls + p * LS + (u + TT * m));
         ctx.sync();
 #pragma unroll
         for (int m = 0; m < E; ++m) ls[(u + TT * m) * LS + p] = v[m].y;
         ctx.sync();
 #pragma unroll
-        for (int m = 0; m < E; ++m) v[m].y = ls[p * LS + (u + TT * m)];
+        for (int m = 0; m < E; ++m) v[m].y = ctx.lds_ld_s(ls + p * LS + (u + TT * m));
+        if constexpr ((SYNC & SYNC_POST) != 0) ctx.sync();
     }
-    fft_line<N, SGN, T>(v, lds, p, u, twr, ctx);  // along c
+    fft_line<N, SGN, T, OLD ? SYNC_PRE : (LAST_POST ? SYNC_POST : 0)>(v, lds, p, u, twr, ctx);  // along c
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -408,6 +434,8 @@ struct TailLineParams {      // tail step 2: x inverse of both, Q = Re(gain) - R
 
 BFSM_HD int mode_of(int i, int n) { return i < n / 2 ? i : i - n; }
 
+template <bool B> struct BoolTag { static constexpr bool value = B; };
+
 // ------------------------------------------------------------------------------------------------------------
 // Kernel bodies.  Workgroup = Wg<N>::THREADS threads, tid = u*N + p.
 // ------------------------------------------------------------------------------------------------------------
@@ -495,50 +523,109 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
     const int d_begin = ctx.by() * prm.per_group;
     int d_end = d_begin + prm.per_group;
     if (d_end > prm.n_dir) d_end = prm.n_dir;
-    // One iteration = one signed direction (j = 2*d + sign).  Phase of this thread's points:
-    // e^{+-i theta} / G = (phx[lx] * phy[ly = p]) * phz[lz = u + T m], conjugated for sign 1.  The phz / phx factors
-    // are wave-uniform scalar loads; the per-lane phy factor of the NEXT iteration is fetched before this
-    // iteration's transform so that its latency hides behind the butterflies.
-    const int j_end = 2 * d_end;
-    cx<T> py = {(T)0, (T)0};
-    if (d_begin < d_end) py = prm.phy[(size_t)(prm.dir0 + d_begin) * N + p];
-    for (int j = 2 * d_begin; j < j_end; ++j) {
-        const int d = j >> 1;
-        const bool conj = (j & 1) != 0;
-        const size_t b = (size_t)(prm.dir0 + d);
-        const cx<T> c0 = cmul(ctx.ldc(prm.phx + b * N + lxi), py);
-        if (j + 1 < j_end) py = prm.phy[(size_t)(prm.dir0 + ((j + 1) >> 1)) * N + p];
-        cx<T> v[E];
+    if constexpr (N >= 64 && KEEP) {
+        // One iteration = one direction; both signs are produced by the same code with the sign a compile-time flag
+        // (e^{+-i theta} / G = (phx[lx] * phy[ly = p]) * phz[lz = u + T m], conjugated for sign 1), so no per-point select
+        // is executed.  The phz / phx factors are wave-uniform scalar loads; the per-lane phy factor of the NEXT direction
+        // is fetched before this direction's transforms so that its latency hides behind the butterflies.
+        cx<T> py = {(T)0, (T)0};
+        if (d_begin < d_end) py = prm.phy[(size_t)(prm.dir0 + d_begin) * N + p];
+        for (int d = d_begin; d < d_end; ++d) {
+            const size_t b = (size_t)(prm.dir0 + d);
+            const cx<T> c0 = cmul(ctx.ldc(prm.phx + b * N + lxi), py);
+            if (d + 1 < d_end) py = prm.phy[(size_t)(prm.dir0 + d + 1) * N + p];
+            // L2 warm-up of the phase-table rows of the next direction.  The tables are read with ordinary loads and
+            // stay in L2 next to the nontemporal streams as long as they fit (<= ~4 MiB per XCD); for larger direction
+            // sets (config 5 on one GPU: 3 x 5.9 MiB) every row would be cold at the top of its iteration and stall all
+            // waves of the workgroup (measured: KA 8.7 -> 11 us per direction; with the warm-up 9.0 for any table size).
+            // One wave touches each 64-byte line of the phz / phy rows one direction ahead; the values are only kept alive
+            // until the first transform is done.  The host enables it where it pays: one workgroup per CU (N = 128) and
+            // tables beyond 3 MiB; with two workgroups per CU (N = 64) the other workgroup already covers the miss.
+            T warm = (T)0;
+            constexpr int EPL = 64 / (int)sizeof(cx<T>), LINES = N / EPL;       // entries per line, lines per row
+            const bool warming = (N % 64 == 0) && 2 * LINES <= 64 && prm.warm_tables != 0 && u == 0 && d + 2 < d_end;
+            if (warming) {
+                const size_t bw = (size_t)(prm.dir0 + d + 2);
+                const int l = tid % 64;
+                const cx<T>* row = (l < LINES) ? prm.phz : prm.phy;
+                warm = row[bw * N + (size_t)(l % LINES) * EPL].x;
+            }
+            auto one_sign = [&](auto conj_tag) {
+                constexpr bool CONJ = decltype(conj_tag)::value;
+                // the second sign re-forms its phase factors from an opaque copy of c0: sharing them between the signs
+                // would keep a whole extra tile of values alive across the first transform (registers: spills)
+#ifndef BFSM_KA_SHARE_PH
+                const cx<T> c0s = CONJ ? ctx.opaque_cx(c0) : c0;
+#else
+                const cx<T> c0s = c0;
+#endif
+                cx<T> v[E];
 #pragma unroll
-        for (int m = 0; m < E; ++m) {
-            const cx<T> ph = cmul(c0, ctx.ldc(prm.phz + b * N + u + TT * m));
-            cx<T> fm;
-            if constexpr (KEEP) fm = fh[m]; else fm = src[(u + TT * m) * N + p];
-            v[m] = conj ? cmulc(fm, ph) : cmul(fm, ph);   // conj(alpha1) f_hat / G  :  alpha1 f_hat / G
-            if constexpr (!KEEP) { if ((m & 3) == 3) ctx.sched_fence(); }   // at most 4 re-read points in flight
-        }
-        // L2 warm-up of the phase-table rows of the direction after next.  The tables are read with ordinary loads and
-        // stay in L2 next to the nontemporal streams as long as they fit (<= ~4 MiB per XCD); for larger direction
-        // sets (config 5 on one GPU: 3 x 5.9 MiB) every row would be cold at the top of its iteration and stall all
-        // waves of the workgroup (measured: KA 8.7 -> 11 us per direction; with the warm-up 9.0 for any table size).
-        // One wave touches each 64-byte line of the phz / phy rows two iterations ahead; the values are only kept alive
-        // until the transform is done.  The host enables it where it pays: one workgroup per CU (N = 128) and tables
-        // beyond 3 MiB; with two workgroups per CU (N = 64) the other workgroup already covers the miss.
-        T warm = (T)0;
-        constexpr int EPL = 64 / (int)sizeof(cx<T>), LINES = N / EPL;       // entries per line, lines per row
-        const bool warming = (N % 64 == 0) && 2 * LINES <= 64 && prm.warm_tables != 0 && u == 0 && j + 2 < j_end && (j & 1) == 0;
-        if (warming) {
-            const size_t bw = (size_t)(prm.dir0 + ((j + 2) >> 1));
-            const int l = tid % 64;
-            const cx<T>* row = (l < LINES) ? prm.phz : prm.phy;
-            warm = row[bw * N + (size_t)(l % LINES) * EPL].x;
-        }
-        fft_tile<N, +1, T>(v, lds, p, u, twr, ctx);
-        if (warming) ctx.keep_alive(warm);
-        cx<T>* dst = (conj ? prm.a2 : prm.a1) + bz * prm.a_bstride + ((size_t)d * prm.planes + lxi) * N * N;
+                for (int m = 0; m < E; ++m) {
+                    const cx<T> ph = cmul(c0s, ctx.ldc(prm.phz + b * N + u + TT * m));
+                    cx<T> fm;
+                    if constexpr (KEEP) fm = fh[m]; else fm = src[(u + TT * m) * N + p];
+                    v[m] = CONJ ? cmulc(fm, ph) : cmul(fm, ph);   // conj(alpha1) f_hat / G  :  alpha1 f_hat / G
+                    if constexpr (!KEEP) { if ((m & 3) == 3) ctx.sched_fence(); }   // at most 4 re-read points in flight
+                }
+                fft_tile<N, +1, T, true>(v, lds, p, u, twr, ctx);
+                cx<T>* dst = (CONJ ? prm.a2 : prm.a1) + bz * prm.a_bstride + ((size_t)d * prm.planes + lxi) * N * N;
 #pragma unroll
-        for (int m = 0; m < E; ++m)   // [y = u + T m][z = p]
-            ctx.template st_stream_at<N % 64 == 0>(dst + (size_t)(u + TT * m) * N, (unsigned)p * (unsigned)sizeof(cx<T>), v[m]);
+                for (int m = 0; m < E; ++m)   // [y = u + T m][z = p]
+                    ctx.template st_stream_at<N % 64 == 0>(dst + (size_t)(u + TT * m) * N, (unsigned)p * (unsigned)sizeof(cx<T>), v[m]);
+            };
+            one_sign(BoolTag<false>{});
+            if (warming) ctx.keep_alive(warm);
+            one_sign(BoolTag<true>{});
+        }
+    } else {
+        // small grids (per-lane tables live in VGPRs) and the split-exchange geometry (N = 128, fp64: at the register
+        // limit): one loop body with a run-time sign
+        // One iteration = one signed direction (j = 2*d + sign).  Phase of this thread's points:
+        // e^{+-i theta} / G = (phx[lx] * phy[ly = p]) * phz[lz = u + T m], conjugated for sign 1.  The phz / phx factors
+        // are wave-uniform scalar loads; the per-lane phy factor of the NEXT iteration is fetched before this
+        // iteration's transform so that its latency hides behind the butterflies.
+        const int j_end = 2 * d_end;
+        cx<T> py = {(T)0, (T)0};
+        if (d_begin < d_end) py = prm.phy[(size_t)(prm.dir0 + d_begin) * N + p];
+        for (int j = 2 * d_begin; j < j_end; ++j) {
+            const int d = j >> 1;
+            const bool conj = (j & 1) != 0;
+            const size_t b = (size_t)(prm.dir0 + d);
+            const cx<T> c0 = cmul(ctx.ldc(prm.phx + b * N + lxi), py);
+            if (j + 1 < j_end) py = prm.phy[(size_t)(prm.dir0 + ((j + 1) >> 1)) * N + p];
+            cx<T> v[E];
+#pragma unroll
+            for (int m = 0; m < E; ++m) {
+                const cx<T> ph = cmul(c0, ctx.ldc(prm.phz + b * N + u + TT * m));
+                cx<T> fm;
+                if constexpr (KEEP) fm = fh[m]; else fm = src[(u + TT * m) * N + p];
+                v[m] = conj ? cmulc(fm, ph) : cmul(fm, ph);   // conj(alpha1) f_hat / G  :  alpha1 f_hat / G
+                if constexpr (!KEEP) { if ((m & 3) == 3) ctx.sched_fence(); }   // at most 4 re-read points in flight
+            }
+            // L2 warm-up of the phase-table rows of the direction after next.  The tables are read with ordinary loads and
+            // stay in L2 next to the nontemporal streams as long as they fit (<= ~4 MiB per XCD); for larger direction
+            // sets (config 5 on one GPU: 3 x 5.9 MiB) every row would be cold at the top of its iteration and stall all
+            // waves of the workgroup (measured: KA 8.7 -> 11 us per direction; with the warm-up 9.0 for any table size).
+            // One wave touches each 64-byte line of the phz / phy rows two iterations ahead; the values are only kept alive
+            // until the transform is done.  The host enables it where it pays: one workgroup per CU (N = 128) and tables
+            // beyond 3 MiB; with two workgroups per CU (N = 64) the other workgroup already covers the miss.
+            T warm = (T)0;
+            constexpr int EPL = 64 / (int)sizeof(cx<T>), LINES = N / EPL;       // entries per line, lines per row
+            const bool warming = (N % 64 == 0) && 2 * LINES <= 64 && prm.warm_tables != 0 && u == 0 && j + 2 < j_end && (j & 1) == 0;
+            if (warming) {
+                const size_t bw = (size_t)(prm.dir0 + ((j + 2) >> 1));
+                const int l = tid % 64;
+                const cx<T>* row = (l < LINES) ? prm.phz : prm.phy;
+                warm = row[bw * N + (size_t)(l % LINES) * EPL].x;
+            }
+            fft_tile<N, +1, T>(v, lds, p, u, twr, ctx);
+            if (warming) ctx.keep_alive(warm);
+            cx<T>* dst = (conj ? prm.a2 : prm.a1) + bz * prm.a_bstride + ((size_t)d * prm.planes + lxi) * N * N;
+#pragma unroll
+            for (int m = 0; m < E; ++m)   // [y = u + T m][z = p]
+                ctx.template st_stream_at<N % 64 == 0>(dst + (size_t)(u + TT * m) * N, (unsigned)p * (unsigned)sizeof(cx<T>), v[m]);
+        }
     }
 }
 
@@ -564,11 +651,11 @@ BFSM_HD void body_gain_line(const GainLineParams<T>& prm, Ctx& ctx) {
     for (int m = 0; m < E; ++m) a[m] = ctx.template ld_stream_at<UNI>(A1 + (size_t)(u + TT * m) * N * N, pl);
 #pragma unroll
     for (int m = 0; m < E; ++m) b[m] = ctx.template ld_stream_at<UNI>(A2 + (size_t)(u + TT * m) * N * N, pl);
-    fft_line_np<N, NPL, +1, T>(a, lds, p, u, twr, ctx);
-    fft_line_np<N, NPL, +1, T>(b, lds, p, u, twr, ctx);
+    fft_line_np<N, NPL, +1, T, false, SYNC_PRE | SYNC_POST>(a, lds, p, u, twr, ctx);
+    fft_line_np<N, NPL, +1, T, false, SYNC_POST>(b, lds, p, u, twr, ctx);
 #pragma unroll
     for (int m = 0; m < E; ++m) a[m] = cmul(a[m], b[m]);
-    fft_line_np<N, NPL, -1, T>(a, lds, p, u, twr, ctx);
+    fft_line_np<N, NPL, -1, T, false, 0>(a, lds, p, u, twr, ctx);
 #pragma unroll
     for (int m = 0; m < E; ++m) ctx.template st_stream_at<UNI>(A1 + (size_t)(u + TT * m) * N * N, pl, a[m]);
 }
@@ -739,6 +826,11 @@ BFSM_HD void body_gain_line_acc_h(const GainLineAccHParams<T>& prm, Ctx& ctx) {
 // KC.  grid = (N planes x, segments of the chunk).  (y,z) part of the forward transform + the direction sum of
 // atomic_tensor_contraction (BoltzmannCUDAKernels.cu:79-123) kept in registers: no atomics, one slab store per
 // workgroup.  A segment never straddles a radial node, so beta1 is applied later, once per slab.
+// The transform is linear and the weights dirw are scalars, so  sum_d dirw_d FFT_yz(P'_d) = FFT_yz(sum_d dirw_d P'_d):
+// the workgroup streams every P'_d of its segment exactly once (the same 1*G*c bytes per direction as transforming each
+// of them), accumulates the weighted sum in registers and transforms it once.  The streaming loop is then a pure
+// HBM read (32 FMAs per tile); rounding order differs from the per-direction form at the 1e-16 (fp64) level.
+// BFSM_KC_PER_DIRECTION restores one (y,z) transform per direction (not possible in the split-exchange geometry).
 template <int N, typename T, class Ctx>
 BFSM_HD void body_gain_fwd(const GainFwdParams<T>& prm, Ctx& ctx) {
     constexpr int E = Wg<N>::E, TT = Wg<N>::T;
@@ -751,14 +843,19 @@ BFSM_HD void body_gain_fwd(const GainFwdParams<T>& prm, Ctx& ctx) {
 #pragma unroll
     for (int m = 0; m < E; ++m) acc[m] = {(T)0, (T)0};
     const Segment seg = prm.segs[prm.seg0 + ctx.by()];
-    if constexpr (!split_tile<N, T>()) {
+#ifdef BFSM_KC_PER_DIRECTION
+    constexpr bool PER_DIRECTION = !split_tile<N, T>();
+#else
+    constexpr bool PER_DIRECTION = false;
+#endif
+    if constexpr (PER_DIRECTION) {
         for (int d = seg.d0; d < seg.d0 + seg.n; ++d) {
             const cx<T>* src = prm.p + (size_t)ctx.bz() * prm.p_bstride + ((size_t)d * N + x) * N * N;
             cx<T> v[E];
 #pragma unroll
             for (int m = 0; m < E; ++m)   // [y = u + T m][z = p]
                 v[m] = ctx.template ld_stream_at<N % 64 == 0>(src + (u + TT * m) * N, (unsigned)p * (unsigned)sizeof(cx<T>));
-            fft_tile<N, -1, T>(v, lds, p, u, twr, ctx);
+            fft_tile<N, -1, T, (N >= 128)>(v, lds, p, u, twr, ctx);
             const T w = prm.dirw[prm.dir0 + d];
 #pragma unroll
             for (int m = 0; m < E; ++m) {
@@ -767,9 +864,6 @@ BFSM_HD void body_gain_fwd(const GainFwdParams<T>& prm, Ctx& ctx) {
             }
         }
     } else {
-        // N = 128 in fp64: accumulators plus a second tile of data exceed the 128 VGPRs of a 1024-thread workgroup.
-        // The transform is linear, so the weighted sum over the segment is formed on the inputs and transformed once
-        // (same bytes read; rounding order differs from the per-direction form at the 1e-16 level).
         for (int d = seg.d0; d < seg.d0 + seg.n; ++d) {
             const cx<T>* src = prm.p + (size_t)ctx.bz() * prm.p_bstride + ((size_t)d * N + x) * N * N;
             const T w = prm.dirw[prm.dir0 + d];

@@ -364,7 +364,9 @@ struct Pipeline {
             const int tw_ = target_workgroups(N, max_batch);
             const int groups_a = tw_ / a_planes > 0 ? tw_ / a_planes : 1;   // <= target: one resident wave of workgroups
             const int per_group_a = (c.n + groups_a - 1) / groups_a;
-            const bool warm = N >= 128 && 3.0 * (double)plan.n_dirs() * N * sizeof(cx<T>) > 3.0 * 1024 * 1024;
+            // phase tables beyond ~3 MiB do not stay in an XCD's L2 next to the streams: KA touches the rows ahead
+            // (N = 64, config 4: 3 x 2.4 MiB of tables, KA 3.88 -> 3.66 ms; N = 128, config 5: 62 -> 52 ms)
+            const bool warm = N >= 64 && 3.0 * (double)plan.n_dirs() * N * sizeof(cx<T>) > 3.0 * 1024 * 1024;
             GainInvParams<T> ka{fhat, a1, a2, phx, phy, phz, tw, c.dir0, c.n, per_group_a, a_bs, a_planes, warm ? 1 : 0};
             const int ga = (c.n + per_group_a - 1) / per_group_a;
             be->mark(BFSM_K_GAIN_INV, 2.0 * c.n * Gc * hfrac);

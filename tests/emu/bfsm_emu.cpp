@@ -31,6 +31,9 @@ struct EmuCtx {
     int uniform(int v, int) const { return v; }
     template <class U> U* lds() const { return reinterpret_cast<U*>(smem); }
     template <class U> U ldc(const U* p) const { return *p; }
+    template <class U> U lds_ld(const U* p) const { return *p; }
+    template <class U> void lds_st(U* p, U v) const { *p = v; }
+    template <class U> U lds_ld_s(const U* p) const { return *p; }
     template <class U> U ld_stream(const U* p) const { return *p; }
     template <class U> void st_stream(U* p, U v) const { *p = v; }
     template <bool UNI, class U> U ld_stream_at(const U* row, unsigned byte_off) const {
@@ -44,6 +47,7 @@ struct EmuCtx {
     void sync();       // workgroup barrier
     void sched_fence() const {}   // compiler scheduling hint on the device; nothing to do on the host
     int opaque(int v) const { return v; }
+    template <class U> U opaque_cx(U v) const { return v; }
     template <class T> void keep_alive(T) const {}
     template <class U> U* uniform_ptr(U* p) const { return p; }
     void wave_sync();  // ordering point inside one wave of 64 threads
