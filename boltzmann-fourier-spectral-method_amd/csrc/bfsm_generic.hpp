@@ -1,0 +1,494 @@
+// bfsm_generic.hpp -- size-generic path of the collision operator: any even Nvx, Nvy, Nvz <= 256 whose prime factors
+// are 2, 3, 5 (non-cubic boxes, N = 48, 96, ...), which the reference plans with cufftPlan3d / cufftPlanMany
+// (Collisions/CUDABoltzmannOperator.cu:86-100) and fftw_plan_dft_3d (Collisions/FFTWBoltzmannOperator.cpp:64-65).
+//
+// The cubic grids N in {16, 32, 64, 128} run on the fused three-kernel pipeline of bfsm_core.hpp (6 array passes per
+// direction); everything else runs here: one batched 1-D mixed-radix Stockham pass per axis, transformed in LDS, with
+// the pointwise steps of the reference fused into the pass that touches the data first
+//     phase multiply (compute_alpha_times_f_hat, BoltzmannCUDAKernels.cu:21-59)  -> load side of the first inverse pass
+//     hadamard_product (Kernels.cu:62-74)                                        -> load side of the first forward pass
+//     beta2 * f_hat (Kernels.cu:126-159)                                         -> load side of the first tail pass
+//     copy_to_complex (Kernels.cu:4-16)                                          -> load side of the first pass of FFT(f)
+// and a deterministic, atomic-free accumulate (atomic_tensor_contraction, Kernels.cu:79-123).  12 array passes per
+// direction: about half the speed of the fused pipeline, all sizes.  Layouts are the reference's own: physical
+// [x][y][z], spectral [lx][ly][lz], z contiguous.
+//
+// Like bfsm_core.hpp the kernel bodies are templates over an execution context, so tests/emu runs the same code on the
+// host.
+#pragma once
+#include <cmath>
+#include <string>
+#include <vector>
+
+#include "bfsm_pipeline.hpp"
+
+namespace bfsm {
+
+constexpr int GEN_MAX_N = 256;
+constexpr int GEN_THREADS = 256;
+
+// load-side fusions of a pass
+enum : int { GEN_PLAIN = 0, GEN_PHASE = 1, GEN_PRODUCT = 2, GEN_REAL = 3, GEN_BETA2 = 4 };
+
+template <typename T>
+struct GenFftParams {
+    const void* in;          // cx<T> arrays [batch][G]; GEN_REAL: const double* [batch][G]; GEN_PHASE / GEN_BETA2: f_hat [G]
+    const cx<T>* in2;        // GEN_PRODUCT: second factor, same shape as in
+    cx<T>* out;              // [batch][G]
+    const cx<T>* tw;         // exp(-2 pi i k / n), k < n, n = length of the transformed axis
+    int nx, ny, nz;
+    int axis;                // 0: x, 1: y, 2: z
+    int sign;                // -1 forward, +1 backward (FFTW convention), unnormalised
+    int C;                   // lines ("columns") per workgroup
+    int n_radix;
+    int radix[8];
+    int mode;
+    // GEN_PHASE: batch member b = 2 * d + s of the chunk; factor phx[d][lx] phy[d][ly] phz[d][lz] (phx carries 1/G),
+    // conjugated for s = 1 (alpha2 = conj(alpha1), FFTWBoltzmannOperator.cpp:219-224)
+    const cx<T>* phx;
+    const cx<T>* phy;
+    const cx<T>* phz;
+    long long dir0;
+    // GEN_BETA2: beta2[|l|^2] (1/G folded)
+    const T* beta2;
+    size_t in_bstride;       // elements between batch members of in / in2 (0: shared)
+    size_t out_bstride;      // elements between batch members of out
+};
+
+template <typename T>
+struct GenAccParams {        // Q_hat[l] (+)= sum_d dirw[d] beta1[r(d)][|l|^2] P_hat[d][l], fixed order (no atomics)
+    const cx<T>* p;          // member d at p + d * p_bstride
+    size_t p_bstride;
+    cx<T>* qhat;             // [G]
+    const T* dirw;           // [shard directions]
+    const int* rdir;         // [shard directions] radial node of each direction
+    const T* beta1;          // [n_gl][n2stride]
+    long long dir0;
+    int n;
+    int n2stride;
+    int first;               // != 0: start from zero instead of from qhat
+    int nx, ny, nz;
+};
+
+template <typename T>
+struct GenCombineParams {    // Q = Re(gain) - Re(loss) * f   (compute_Q_total, Kernels.cu:162-177)
+    const cx<T>* g;
+    const cx<T>* l;
+    const double* f;
+    double* Q;
+    size_t G;
+    int with_loss;
+};
+
+// Fourier mode of index i on an axis of n points (FFTWBoltzmannOperator.cpp:50-57)
+BFSM_HD int gen_mode(int i, int n) { return i < n / 2 ? i : i - n; }
+
+template <int R, typename T>
+BFSM_HD void gen_dft(cx<T>* x, int sgn) {
+    // direct small DFTs, X[k] = sum_j x[j] exp(sgn * 2 pi i j k / R)
+    if constexpr (R == 2) {
+        const cx<T> a = x[0], b = x[1];
+        x[0] = cadd(a, b);
+        x[1] = csub(a, b);
+    } else if constexpr (R == 4) {
+        const cx<T> a = cadd(x[0], x[2]), b = csub(x[0], x[2]), c = cadd(x[1], x[3]), d = csub(x[1], x[3]);
+        const cx<T> id = sgn > 0 ? cx<T>{-d.y, d.x} : cx<T>{d.y, -d.x};     // sgn * i * d
+        x[0] = cadd(a, c);
+        x[2] = csub(a, c);
+        x[1] = cadd(b, id);
+        x[3] = csub(b, id);
+    } else if constexpr (R == 3) {
+        const T c = (T)-0.5, s = (T)(sgn * 0.86602540378443864676);
+        const cx<T> t1 = cadd(x[1], x[2]), t2 = csub(x[1], x[2]);
+        const cx<T> m = {x[0].x + c * t1.x, x[0].y + c * t1.y};
+        const cx<T> r = {-s * t2.y, s * t2.x};                               // i * s * t2
+        x[0] = cadd(x[0], t1);
+        x[1] = cadd(m, r);
+        x[2] = csub(m, r);
+    } else {   // R == 5
+        const T c1 = (T)0.30901699437494742410, c2 = (T)-0.80901699437494742410;
+        const T s1 = (T)(sgn * 0.95105651629515357212), s2 = (T)(sgn * 0.58778525229247312917);
+        const cx<T> a1 = cadd(x[1], x[4]), b1 = csub(x[1], x[4]), a2 = cadd(x[2], x[3]), b2 = csub(x[2], x[3]);
+        const cx<T> m1 = {x[0].x + c1 * a1.x + c2 * a2.x, x[0].y + c1 * a1.y + c2 * a2.y};
+        const cx<T> m2 = {x[0].x + c2 * a1.x + c1 * a2.x, x[0].y + c2 * a1.y + c1 * a2.y};
+        const cx<T> r1 = {-(s1 * b1.y + s2 * b2.y), s1 * b1.x + s2 * b2.x};  // i * (s1 b1 + s2 b2)
+        const cx<T> r2 = {-(s2 * b1.y - s1 * b2.y), s2 * b1.x - s1 * b2.x};  // i * (s2 b1 - s1 b2)
+        x[0] = cadd(x[0], cadd(a1, a2));
+        x[1] = cadd(m1, r1);
+        x[4] = csub(m1, r1);
+        x[2] = cadd(m2, r2);
+        x[3] = csub(m2, r2);
+    }
+}
+
+// One Stockham pass of radix R over C lines of n points held in LDS as [point][line] (row stride LS).
+template <int R, typename T, class Ctx>
+BFSM_HD void gen_pass(const cx<T>* src, cx<T>* dst, const cx<T>* tw, int n, int ns, int C, int LS, int sgn, Ctx& ctx) {
+    const int m = n / R, tasks = m * C;
+    for (int t = ctx.tid(); t < tasks; t += ctx.nthreads()) {
+        const int col = t % C, j = t / C;
+        const int k = j % ns;                          // position inside the sub-transform done so far
+        const int tstep = n / (ns * R);                // twiddle exp(sgn 2 pi i k q / (ns R)) = tw[k q tstep]
+        cx<T> x[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            x[q] = src[(j + q * m) * LS + col];
+            if (q > 0) {
+                const cx<T> w = tw[(k * q * tstep) % n];
+                x[q] = sgn < 0 ? cmul(x[q], w) : cmulc(x[q], w);
+            }
+        }
+        gen_dft<R, T>(x, sgn);
+        const int j0 = (j / ns) * ns * R + k;
+#pragma unroll
+        for (int q = 0; q < R; ++q) dst[(j0 + q * ns) * LS + col] = x[q];
+    }
+}
+
+// Batched 1-D transform along one axis.  grid = (column blocks, batch).  Workgroup: GEN_THREADS threads, LDS = two
+// buffers of n x (C + 1) complex.
+template <typename T, class Ctx>
+BFSM_HD void body_gen_fft(const GenFftParams<T>& prm, Ctx& ctx) {
+    const int nx = prm.nx, ny = prm.ny, nz = prm.nz;
+    const int axis = prm.axis;
+    const int n = axis == 0 ? nx : (axis == 1 ? ny : nz);
+    const size_t G = (size_t)nx * ny * nz;
+    const int ncols = (int)(G / (size_t)n);
+    const int C = prm.C, LS = C + 1;
+    const int col0 = ctx.bx() * C;
+    const int b = ctx.by();
+    cx<T>* buf0 = ctx.template lds<cx<T>>();
+    cx<T>* buf1 = buf0 + (size_t)n * LS;
+    const int total = n * C;
+    // element (pt, col) of this workgroup's block -> linear index inside one array
+    auto index_of = [&](int pt, int col) -> size_t {
+        if (axis == 0) return (size_t)pt * ny * nz + col;                         // col = y * nz + z
+        if (axis == 1) return ((size_t)(col / nz) * ny + pt) * nz + (col % nz);   // col = x * nz + z
+        return (size_t)col * nz + pt;                                             // col = x * ny + y
+    };
+    for (int e = ctx.tid(); e < total; e += ctx.nthreads()) {
+        // lanes run along the contiguous (z) direction of memory
+        const int pt = axis == 2 ? e % n : e / C, cl = axis == 2 ? e / n : e % C;
+        const int col = col0 + cl;
+        cx<T> v = {(T)0, (T)0};
+        if (col < ncols) {
+            const size_t idx = index_of(pt, col);
+            if (prm.mode == GEN_REAL) {
+                v.x = (T) static_cast<const double*>(prm.in)[(size_t)b * prm.in_bstride + idx];
+            } else {
+                v = static_cast<const cx<T>*>(prm.in)[(size_t)b * prm.in_bstride + idx];
+                if (prm.mode == GEN_PRODUCT) {
+                    v = cmul(v, prm.in2[(size_t)b * prm.in_bstride + idx]);
+                } else if (prm.mode == GEN_PHASE || prm.mode == GEN_BETA2) {
+                    const int iz = (int)(idx % nz), iy = (int)((idx / nz) % ny), ix = (int)(idx / ((size_t)nz * ny));
+                    if (prm.mode == GEN_PHASE) {
+                        const size_t d = (size_t)(prm.dir0 + (b >> 1));
+                        const cx<T> ph = cmul(cmul(prm.phx[d * nx + ix], prm.phy[d * ny + iy]), prm.phz[d * nz + iz]);
+                        v = (b & 1) ? cmulc(v, ph) : cmul(v, ph);
+                    } else {
+                        const int mx = gen_mode(ix, nx), my = gen_mode(iy, ny), mz = gen_mode(iz, nz);
+                        const T b2 = prm.beta2[mx * mx + my * my + mz * mz];
+                        v = {b2 * v.x, b2 * v.y};
+                    }
+                }
+            }
+        }
+        buf0[pt * LS + cl] = v;
+    }
+    ctx.sync();
+    cx<T>* src = buf0;
+    cx<T>* dst = buf1;
+    int ns = 1;
+    for (int r = 0; r < prm.n_radix; ++r) {
+        const int R = prm.radix[r];
+        if (R == 2) gen_pass<2, T>(src, dst, prm.tw, n, ns, C, LS, prm.sign, ctx);
+        else if (R == 3) gen_pass<3, T>(src, dst, prm.tw, n, ns, C, LS, prm.sign, ctx);
+        else if (R == 4) gen_pass<4, T>(src, dst, prm.tw, n, ns, C, LS, prm.sign, ctx);
+        else gen_pass<5, T>(src, dst, prm.tw, n, ns, C, LS, prm.sign, ctx);
+        ns *= R;
+        ctx.sync();
+        cx<T>* t = src; src = dst; dst = t;
+    }
+    for (int e = ctx.tid(); e < total; e += ctx.nthreads()) {
+        const int pt = axis == 2 ? e % n : e / C, cl = axis == 2 ? e / n : e % C;
+        const int col = col0 + cl;
+        if (col < ncols) prm.out[(size_t)b * prm.out_bstride + index_of(pt, col)] = src[pt * LS + cl];
+    }
+}
+
+template <typename T, class Ctx>
+BFSM_HD void body_gen_acc(const GenAccParams<T>& prm, Ctx& ctx) {
+    const size_t G = (size_t)prm.nx * prm.ny * prm.nz;
+    const size_t idx = (size_t)ctx.bx() * ctx.nthreads() + ctx.tid();
+    if (idx >= G) return;
+    const int iz = (int)(idx % prm.nz), iy = (int)((idx / prm.nz) % prm.ny), ix = (int)(idx / ((size_t)prm.nz * prm.ny));
+    const int mx = gen_mode(ix, prm.nx), my = gen_mode(iy, prm.ny), mz = gen_mode(iz, prm.nz);
+    const int n2 = mx * mx + my * my + mz * mz;
+    cx<T> q = prm.first ? cx<T>{(T)0, (T)0} : prm.qhat[idx];
+    for (int d = 0; d < prm.n; ++d) {
+        const size_t b = (size_t)(prm.dir0 + d);
+        const T w = prm.dirw[b] * prm.beta1[(size_t)prm.rdir[b] * prm.n2stride + n2];
+        const cx<T> t = prm.p[(size_t)d * prm.p_bstride + idx];
+        q.x += w * t.x;
+        q.y += w * t.y;
+    }
+    prm.qhat[idx] = q;
+}
+
+template <typename T, class Ctx>
+BFSM_HD void body_gen_combine(const GenCombineParams<T>& prm, Ctx& ctx) {
+    const size_t idx = (size_t)ctx.bx() * ctx.nthreads() + ctx.tid();
+    if (idx >= prm.G) return;
+    double q = (double)prm.g[idx].x;
+    if (prm.with_loss) q -= (double)prm.l[idx].x * prm.f[idx];
+    prm.Q[idx] = q;
+}
+
+enum class GK { Fft, Acc, Combine };
+
+inline bool gen_factor(int n, std::vector<int>& radix) {
+    radix.clear();
+    if (n < 2 || n > GEN_MAX_N) return false;
+    while (n % 4 == 0) { radix.push_back(4); n /= 4; }
+    while (n % 2 == 0) { radix.push_back(2); n /= 2; }
+    while (n % 3 == 0) { radix.push_back(3); n /= 3; }
+    while (n % 5 == 0) { radix.push_back(5); n /= 5; }
+    return n == 1 && radix.size() <= 8;
+}
+
+// grids the generic path serves
+inline bool gen_supported(int nx, int ny, int nz) {
+    std::vector<int> r;
+    for (int n : {nx, ny, nz})
+        if (n < 4 || n % 2 != 0 || !gen_factor(n, r)) return false;
+    return true;
+}
+
+// Backend additionally supplies:
+//   template <GK kind, typename T, class P> void launch_gen(int grid_x, int grid_y, int threads, size_t lds_bytes, const P&)
+template <typename T, class Backend>
+struct GenericPipeline {
+    PlanInfo plan;            // N = 0 marks a generic plan; directions, shard and chunks as in the fused pipeline
+    Backend* be = nullptr;
+    int nx = 0, ny = 0, nz = 0;
+    size_t G = 0;
+    int n_gl = 0;
+    int chunk = 1;            // directions resident at once
+    int max_batch = 1;
+    int n2stride = 0;
+    cx<T>* fhat = nullptr;    // [G]
+    cx<T>* qhat = nullptr;    // [G]
+    cx<T>* tail = nullptr;    // [2][G]: gain, loss
+    cx<T>* a = nullptr;       // [2 * chunk][G]: A1, A2 interleaved per direction; P in the even members
+    cx<T>* tw[3] = {nullptr, nullptr, nullptr};
+    cx<T>* phx = nullptr;
+    cx<T>* phy = nullptr;
+    cx<T>* phz = nullptr;
+    T* dirw = nullptr;
+    int* rdir = nullptr;
+    T* beta1 = nullptr;
+    T* beta2 = nullptr;
+    std::vector<int> radix[3];
+
+    template <typename U>
+    bool dev_copy(U*& dst, const std::vector<U>& src) {
+        dst = (U*)be->alloc((src.empty() ? 1 : src.size()) * sizeof(U));
+        if (!dst) return false;
+        if (!src.empty()) be->upload(dst, src.data(), src.size() * sizeof(U));
+        return true;
+    }
+
+    int init(const bfsm_desc& d, Backend* backend, std::string& err) {
+        be = backend;
+        nx = d.nvx; ny = d.nvy; nz = d.nvz;
+        G = (size_t)nx * ny * nz;
+        n_gl = d.n_gl;
+        max_batch = d.max_batch > 1 ? d.max_batch : 1;
+        if (!gen_factor(nx, radix[0]) || !gen_factor(ny, radix[1]) || !gen_factor(nz, radix[2])) {
+            err = "grid size without a kernel";
+            return BFSM_ERR_UNSUPPORTED;
+        }
+        const long long B = (long long)d.n_gl * d.n_sph;
+        plan = PlanInfo();
+        plan.N = 0;
+        plan.Gtot = G;
+        plan.precision = d.precision;
+        plan.n_gl = d.n_gl; plan.n_sph = d.n_sph; plan.sph_eff = d.n_sph;
+        if (d.dir_begin == 0 && d.dir_end == 0) { plan.full_begin = 0; plan.full_end = B; }
+        else { plan.full_begin = d.dir_begin; plan.full_end = d.dir_end; }
+        plan.dir_begin = plan.full_begin; plan.dir_end = plan.full_end;
+        const long long nd = plan.n_dirs();
+        // directions resident at once: bounded by max_chunk (default 256) and by 8 GiB of A1 / A2 scratch
+        long long c = d.max_chunk > 0 ? d.max_chunk : 256;
+        const long long by_mem = (long long)((8.0 * 1024 * 1024 * 1024) / (2.0 * (double)G * sizeof(cx<T>)));
+        if (c > by_mem) c = by_mem;
+        if (c > 32767) c = 32767;           // 2 * chunk is a grid dimension
+        if (c > nd) c = nd;
+        if (c < 1) c = 1;
+        chunk = (int)c;
+        plan.max_chunk = chunk;
+        plan.largest_chunk = nd > 0 ? chunk : 0;
+        for (long long o = 0; o < nd; o += chunk) {
+            Chunk ck{};
+            ck.dir0 = o;
+            ck.n = (int)(o + chunk <= nd ? chunk : nd - o);
+            plan.chunks.push_back(ck);
+        }
+        const int hx = nx - nx / 2, hy = ny - ny / 2, hz = nz - nz / 2;   // largest |mode| per axis
+        n2stride = hx * hx + hy * hy + hz * hz + 1;
+        plan.n2stride = n2stride;
+        // tables (host, long double trigonometry like the fused pipeline)
+        const double pi = 3.14159265358979323846;
+        const long double PI_L = 3.141592653589793238462643383279502884L;
+        const double fft_scale = 1.0 / (double)G;
+        bool ok = true;
+        const int nn[3] = {nx, ny, nz};
+        for (int ax = 0; ax < 3; ++ax) {
+            std::vector<cx<T>> t(nn[ax]);
+            for (int k = 0; k < nn[ax]; ++k) {
+                const long double ang = -2.0L * PI_L * (long double)k / (long double)nn[ax];
+                t[k] = {(T)cosl(ang), (T)sinl(ang)};
+            }
+            ok = ok && dev_copy(tw[ax], t);
+        }
+        std::vector<cx<T>> hx_((size_t)nd * nx), hy_((size_t)nd * ny), hz_((size_t)nd * nz);
+        std::vector<T> hw((size_t)nd);
+        std::vector<int> hr((size_t)nd);
+        for (long long i = 0; i < nd; ++i) {
+            const long long b = plan.dir_begin + i;
+            const int r = (int)(b / d.n_sph), s = (int)(b % d.n_sph);
+            const long double k = -((long double)pi / (2.0L * (long double)d.L)) * (long double)d.gl_nodes[r];
+            auto fill = [&](std::vector<cx<T>>& dst, int n, double sig, double scale) {
+                for (int j = 0; j < n; ++j) {
+                    const int l = j < n / 2 ? j : j - n;
+                    const long double ang = k * (long double)l * (long double)sig;
+                    dst[(size_t)i * n + j] = {(T)(scale * (double)cosl(ang)), (T)(scale * (double)sinl(ang))};
+                }
+            };
+            fill(hx_, nx, d.sx[s], fft_scale);
+            fill(hy_, ny, d.sy[s], 1.0);
+            fill(hz_, nz, d.sz[s], 1.0);
+            hw[(size_t)i] = (T)(fft_scale * d.gl_wts[r] * d.sph_wts[s] * std::pow(d.gl_nodes[r], d.gamma + 2));
+            hr[(size_t)i] = r;
+        }
+        std::vector<T> b1((size_t)d.n_gl * n2stride), b2v((size_t)n2stride);
+        for (int n2 = 0; n2 < n2stride; ++n2) {
+            const double norm_l = std::sqrt((double)n2);
+            double acc = 0;
+            for (int r = 0; r < d.n_gl; ++r) {
+                b1[(size_t)r * n2stride + n2] = (T)(4 * pi * d.b_gamma * sincc_ref(pi * d.gl_nodes[r] * norm_l / (2 * d.L)));
+                acc += 16 * pi * pi * d.b_gamma * d.gl_wts[r] * std::pow(d.gl_nodes[r], d.gamma + 2) *
+                       sincc_ref(pi * d.gl_nodes[r] * norm_l / d.L);
+            }
+            b2v[n2] = (T)(fft_scale * acc);
+        }
+        ok = ok && dev_copy(phx, hx_) && dev_copy(phy, hy_) && dev_copy(phz, hz_) && dev_copy(dirw, hw) && dev_copy(rdir, hr);
+        ok = ok && dev_copy(beta1, b1) && dev_copy(beta2, b2v);
+        ok = ok && (fhat = (cx<T>*)be->alloc(G * sizeof(cx<T>)));
+        ok = ok && (qhat = (cx<T>*)be->alloc(G * sizeof(cx<T>)));
+        ok = ok && (tail = (cx<T>*)be->alloc(2 * G * sizeof(cx<T>)));
+        ok = ok && (a = (cx<T>*)be->alloc((size_t)2 * chunk * G * sizeof(cx<T>)));
+        if (!ok) { err = "device allocation failed"; return BFSM_ERR_NOMEM; }
+        return BFSM_OK;
+    }
+
+    void destroy() {
+        if (!be) return;
+        void* ptrs[] = {fhat, qhat, tail, a, tw[0], tw[1], tw[2], phx, phy, phz, dirw, rdir, beta1, beta2};
+        for (void* p : ptrs) if (p) be->release(p);
+        fhat = qhat = tail = a = phx = phy = phz = nullptr;
+        tw[0] = tw[1] = tw[2] = nullptr;
+        dirw = beta1 = beta2 = nullptr;
+        rdir = nullptr;
+    }
+
+    int axis_len(int ax) const { return ax == 0 ? nx : (ax == 1 ? ny : nz); }
+    bool fuse_reduce() const { return false; }
+
+    // one axis pass over `batch` arrays; member b of in / out sits at + b * in_bstride / + b * out_bstride.  A pass may
+    // run in place: every workgroup reads its whole block of lines into LDS before it stores the same block.
+    void pass(const void* in, const cx<T>* in2, cx<T>* out, int batch, int axis, int sign, int mode, size_t in_bstride,
+              size_t out_bstride, long long dir0 = 0) {
+        GenFftParams<T> p{};
+        p.in = in; p.in2 = in2; p.out = out; p.tw = tw[axis];
+        p.nx = nx; p.ny = ny; p.nz = nz; p.axis = axis; p.sign = sign;
+        const int n = axis_len(axis);
+        const int ncols = (int)(G / (size_t)n);
+        int C = n <= 128 ? 16 : 8;
+        if (axis == 1 && nz % C != 0) C = nz % 8 == 0 ? 8 : (nz % 4 == 0 ? 4 : 2);   // a block never straddles an x plane
+        if (C > ncols) C = ncols;
+        p.C = C;
+        p.n_radix = (int)radix[axis].size();
+        for (int i = 0; i < p.n_radix; ++i) p.radix[i] = radix[axis][i];
+        p.mode = mode; p.phx = phx; p.phy = phy; p.phz = phz; p.dir0 = dir0; p.beta2 = beta2;
+        p.in_bstride = in_bstride; p.out_bstride = out_bstride;
+        const size_t lds = (size_t)2 * n * (C + 1) * sizeof(cx<T>);
+        be->template launch_gen<GK::Fft, T>((ncols + C - 1) / C, batch, GEN_THREADS, lds, p);
+    }
+
+    // f_hat = FFT(f), then the gain term of this shard into qhat   (CUDABoltzmannOperator.cu:131-191)
+    void gain_partial(const double* f_dev, int nb = 1, bool = true) {
+        (void)nb;
+        const double Gc = (double)G * sizeof(cx<T>);
+        be->mark(BFSM_K_FFT_F, 5.5 * Gc);
+        pass(f_dev, nullptr, fhat, 1, 2, -1, GEN_REAL, 0, 0);
+        be->mark(-1, 0); pass(fhat, nullptr, fhat, 1, 1, -1, GEN_PLAIN, 0, 0);
+        be->mark(-1, 0); pass(fhat, nullptr, fhat, 1, 0, -1, GEN_PLAIN, 0, 0);
+        bool first = true;
+        for (const Chunk& c : plan.chunks) {
+            const int nb2 = 2 * c.n;
+            // A1, A2 = IFFT(alpha f_hat / G), IFFT(conj(alpha) f_hat / G): members 2d, 2d + 1 of `a`
+            be->mark(BFSM_K_GAIN_INV, 11.0 * c.n * Gc);
+            pass(fhat, nullptr, a, nb2, 0, +1, GEN_PHASE, 0, G, c.dir0);
+            be->mark(-1, 0); pass(a, nullptr, a, nb2, 1, +1, GEN_PLAIN, G, G);
+            be->mark(-1, 0); pass(a, nullptr, a, nb2, 2, +1, GEN_PLAIN, G, G);
+            // P_hat = FFT(A1 * A2): the product is formed on the load side of the first forward pass and written over
+            // A1 (members 2d, stride 2G), then transformed in place
+            be->mark(BFSM_K_GAIN_LINE, 8.0 * c.n * Gc);
+            pass(a, a + G, a, c.n, 2, -1, GEN_PRODUCT, 2 * G, 2 * G);
+            be->mark(-1, 0); pass(a, nullptr, a, c.n, 1, -1, GEN_PLAIN, 2 * G, 2 * G);
+            be->mark(-1, 0); pass(a, nullptr, a, c.n, 0, -1, GEN_PLAIN, 2 * G, 2 * G);
+            GenAccParams<T> ka{a, 2 * G, qhat, dirw, rdir, beta1, c.dir0, c.n, n2stride, first ? 1 : 0, nx, ny, nz};
+            be->mark(BFSM_K_GAIN_FWD, (1.0 * c.n + 2.0) * Gc);
+            be->template launch_gen<GK::Acc, T>((int)((G + GEN_THREADS - 1) / GEN_THREADS), 1, GEN_THREADS, 0, ka);
+            first = false;
+        }
+        if (first) {   // empty shard: qhat = 0
+            GenAccParams<T> ka{a, 2 * G, qhat, dirw, rdir, beta1, 0, 0, n2stride, 1, nx, ny, nz};
+            be->mark(-1, 0);
+            be->template launch_gen<GK::Acc, T>((int)((G + GEN_THREADS - 1) / GEN_THREADS), 1, GEN_THREADS, 0, ka);
+        }
+    }
+
+    // loss term + final inverse transforms + combine   (CUDABoltzmannOperator.cu:193-216)
+    void finish(double* Q_dev, const double* f_dev, bool with_loss = true, int nb = 1, bool = false) {
+        (void)nb;
+        const double Gc = (double)G * sizeof(cx<T>);
+        cx<T>* tg = tail;
+        cx<T>* tl = tail + G;
+        be->mark(BFSM_K_TAIL, (with_loss ? 12.0 : 6.0) * Gc);
+        pass(qhat, nullptr, tg, 1, 0, +1, GEN_PLAIN, 0, 0);
+        be->mark(-1, 0); pass(tg, nullptr, tg, 1, 1, +1, GEN_PLAIN, 0, 0);
+        be->mark(-1, 0); pass(tg, nullptr, tg, 1, 2, +1, GEN_PLAIN, 0, 0);
+        if (with_loss) {
+            be->mark(-1, 0); pass(fhat, nullptr, tl, 1, 0, +1, GEN_BETA2, 0, 0);
+            be->mark(-1, 0); pass(tl, nullptr, tl, 1, 1, +1, GEN_PLAIN, 0, 0);
+            be->mark(-1, 0); pass(tl, nullptr, tl, 1, 2, +1, GEN_PLAIN, 0, 0);
+        }
+        GenCombineParams<T> kc{tg, tl, f_dev, Q_dev, G, with_loss ? 1 : 0};
+        be->mark(-1, 0);
+        be->template launch_gen<GK::Combine, T>((int)((G + GEN_THREADS - 1) / GEN_THREADS), 1, GEN_THREADS, 0, kc);
+    }
+
+    // In-place batched 3-D transform on user data (bfsm_fft3d); natural layouts on both sides
+    int fft3d(cx<T>* data, int batch, int sign) {
+        const int order[3] = {2, 1, 0};
+        for (int i = 0; i < 3; ++i) {
+            be->mark(-1, 0);
+            pass(data, nullptr, data, batch, sign < 0 ? order[i] : order[2 - i], sign, GEN_PLAIN, G, G);
+        }
+        return BFSM_OK;
+    }
+};
+
+}  // namespace bfsm

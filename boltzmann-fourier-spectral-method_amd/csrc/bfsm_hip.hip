@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "bfsm_pipeline.hpp"
+#include "bfsm_generic.hpp"
 
 #ifndef BFSM_F32_N64_WAVES
 #define BFSM_F32_N64_WAVES 4
@@ -219,6 +220,16 @@ __global__ void __launch_bounds__((kernel_threads<kind, N>()), (kernel_min_waves
     else if constexpr (kind == K::GainLineAccH) body_gain_line_acc_h<N, T>(prm, ctx);
 }
 
+// size-generic path (bfsm_generic.hpp): runtime sizes, 256 threads, dynamic LDS
+template <GK kind, typename T, class P>
+__global__ void __launch_bounds__(GEN_THREADS) bfsm_gen_kernel(const P prm) {
+    extern __shared__ __align__(16) unsigned char bfsm_smem[];
+    DevCtx ctx{bfsm_smem};
+    if constexpr (kind == GK::Fft) body_gen_fft<T>(prm, ctx);
+    else if constexpr (kind == GK::Acc) body_gen_acc<T>(prm, ctx);
+    else if constexpr (kind == GK::Combine) body_gen_combine<T>(prm, ctx);
+}
+
 // ---- HIP backend -----------------------------------------------------------------------------------------------
 struct HipBackend {
     hipStream_t stream = nullptr;
@@ -286,6 +297,28 @@ struct HipBackend {
         pend_kind = -1;
     }
 
+    template <GK kind, typename T, class P>
+    void launch_gen(int gx, int gy, int threads, size_t lds, const P& prm) {
+        if (gx <= 0 || gy <= 0) return;
+        auto fn = bfsm_gen_kernel<kind, T, P>;
+        if (lds > 48 * 1024) {
+            static std::atomic<unsigned long long> done{0};
+            const unsigned long long bit = 1ull << (device & 63);
+            if (!(done.load(std::memory_order_relaxed) & bit)) {
+                BFSM_NOTE(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                done.fetch_or(bit, std::memory_order_relaxed);
+            }
+        }
+        Rec rec{pend_kind, pend_bytes, nullptr, nullptr};
+        const bool timed = profile && pend_kind >= 0;
+        if (timed) { rec.e0 = next_event(); rec.e1 = next_event(); BFSM_NOTE(hipEventRecord(rec.e0, stream)); }
+        void* args[] = {const_cast<void*>(static_cast<const void*>(&prm))};
+        BFSM_NOTE(hipLaunchKernel(reinterpret_cast<const void*>(fn), dim3((unsigned)gx, (unsigned)gy, 1), dim3((unsigned)threads, 1, 1),
+                                  args, lds, stream));
+        if (timed) { BFSM_NOTE(hipEventRecord(rec.e1, stream)); recs.push_back(rec); }
+        pend_kind = -1;
+    }
+
     template <K kind, typename T, class P>
     void launch(int gx, int gy, int gz, const P& prm, int N) {
         if (gx <= 0 || gy <= 0 || gz <= 0) return;
@@ -312,7 +345,15 @@ struct bfsm_plan {
     bfsm::HipBackend be;
     bfsm::Pipeline<double, bfsm::HipBackend>* p64 = nullptr;
     bfsm::Pipeline<float, bfsm::HipBackend>* p32 = nullptr;
+    bfsm::GenericPipeline<double, bfsm::HipBackend>* g64 = nullptr;   // grids outside the fused pipeline's sizes
+    bfsm::GenericPipeline<float, bfsm::HipBackend>* g32 = nullptr;
     bfsm::PlanInfo info;
+    size_t G = 0;
+    // calls fn(pipeline) on whichever of the four pipelines this handle owns
+    template <class F>
+    void with(F&& fn) {
+        if (p64) fn(*p64); else if (p32) fn(*p32); else if (g64) fn(*g64); else if (g32) fn(*g32);
+    }
     std::string err;
     bfsm_counters counters{};
     bool full_shard = true;
@@ -378,7 +419,18 @@ static int create_impl(const bfsm_desc* desc, bfsm_handle* out, bfsm_plan*& h) {
     h->desc = *desc;
     h->be.profile = (desc->flags & BFSM_FLAG_PROFILE) != 0;
     h->be.device = desc->device;
-    if (desc->precision == BFSM_F64) {
+    h->G = (size_t)desc->nvx * desc->nvy * desc->nvz;
+    if (!bfsm::fused_grid(*desc)) {
+        if (desc->precision == BFSM_F64) {
+            h->g64 = new bfsm::GenericPipeline<double, bfsm::HipBackend>();
+            rc = h->g64->init(*desc, &h->be, err);
+            h->info = h->g64->plan;
+        } else {
+            h->g32 = new bfsm::GenericPipeline<float, bfsm::HipBackend>();
+            rc = h->g32->init(*desc, &h->be, err);
+            h->info = h->g32->plan;
+        }
+    } else if (desc->precision == BFSM_F64) {
         h->p64 = new bfsm::Pipeline<double, bfsm::HipBackend>();
         rc = h->p64->init(*desc, &h->be, err);
         h->info = h->p64->plan;
@@ -447,7 +499,7 @@ int bfsm_gain_partial(bfsm_handle h, const double* f_dev, void* stream) {
         if (rc) return rc;
         if (!f_dev) return fail(h, BFSM_ERR_INVALID, "null f");
         h->be.begin_eval();
-        if (h->p64) h->p64->gain_partial(f_dev); else h->p32->gain_partial(f_dev);
+        h->with([&](auto& p) { p.gain_partial(f_dev); });
         return check_hip(h, "bfsm_gain_partial");
     )
 }
@@ -459,7 +511,7 @@ int bfsm_finish(bfsm_handle h, double* Q_dev, const double* f_dev, void* stream)
         int rc = enter(h, g, stream);
         if (rc) return rc;
         if (!f_dev || !Q_dev) return fail(h, BFSM_ERR_INVALID, "null f or Q");
-        if (h->p64) h->p64->finish(Q_dev, f_dev); else h->p32->finish(Q_dev, f_dev);
+        h->with([&](auto& p) { p.finish(Q_dev, f_dev); });
         return check_hip(h, "bfsm_finish");
     )
 }
@@ -471,7 +523,7 @@ int bfsm_finish_partial(bfsm_handle h, double* Q_dev, const double* f_dev, int w
         int rc = enter(h, g, stream);
         if (rc) return rc;
         if (!f_dev || !Q_dev) return fail(h, BFSM_ERR_INVALID, "null f or Q");
-        if (h->p64) h->p64->finish(Q_dev, f_dev, with_loss != 0); else h->p32->finish(Q_dev, f_dev, with_loss != 0);
+        h->with([&](auto& p) { p.finish(Q_dev, f_dev, with_loss != 0); });
         return check_hip(h, "bfsm_finish_partial");
     )
 }
@@ -484,12 +536,17 @@ int bfsm_collide_batch_async(bfsm_handle h, double* Q_dev, const double* f_dev, 
         if (rc) return rc;
         if (!f_dev || !Q_dev) return fail(h, BFSM_ERR_INVALID, "null f or Q");
         if (!h->full_shard) return fail(h, BFSM_ERR_INVALID, "batched evaluation needs a handle that owns all directions");
-        const int cap = h->p64 ? h->p64->max_batch : h->p32->max_batch;
+        int cap = 1;
+        h->with([&](auto& p) { cap = p.max_batch; });
         if (n_batch < 1 || n_batch > cap)
             return fail(h, BFSM_ERR_INVALID, "n_batch must be in [1, max_batch of the descriptor]");
         h->be.begin_eval();
-        if (h->p64) { const bool fu = h->p64->fuse_reduce(); h->p64->gain_partial(f_dev, n_batch, !fu); h->p64->finish(Q_dev, f_dev, true, n_batch, fu); }
-        else { const bool fu = h->p32->fuse_reduce(); h->p32->gain_partial(f_dev, n_batch, !fu); h->p32->finish(Q_dev, f_dev, true, n_batch, fu); }
+        if (h->g64 || h->g32) {      // the size-generic path evaluates the members one after the other
+            for (int i = 0; i < n_batch; ++i)
+                h->with([&](auto& p) { p.gain_partial(f_dev + (size_t)i * h->G); p.finish(Q_dev + (size_t)i * h->G, f_dev + (size_t)i * h->G); });
+        } else {
+            h->with([&](auto& p) { const bool fu = p.fuse_reduce(); p.gain_partial(f_dev, n_batch, !fu); p.finish(Q_dev, f_dev, true, n_batch, fu); });
+        }
         return check_hip(h, "bfsm_collide_batch");
     )
 }
@@ -516,8 +573,7 @@ int bfsm_collide_partial_async(bfsm_handle h, double* Q_dev, const double* f_dev
         if (!f_dev || !Q_dev) return fail(h, BFSM_ERR_INVALID, "null f or Q");
         h->be.begin_eval();
         // gain kernels, then the tail; with few slabs the reduce is fused into its first kernel (qhat is not written then)
-        if (h->p64) { const bool fu = h->p64->fuse_reduce(); h->p64->gain_partial(f_dev, 1, !fu); h->p64->finish(Q_dev, f_dev, with_loss != 0, 1, fu); }
-        else { const bool fu = h->p32->fuse_reduce(); h->p32->gain_partial(f_dev, 1, !fu); h->p32->finish(Q_dev, f_dev, with_loss != 0, 1, fu); }
+        h->with([&](auto& p) { const bool fu = p.fuse_reduce(); p.gain_partial(f_dev, 1, !fu); p.finish(Q_dev, f_dev, with_loss != 0, 1, fu); });
         return check_hip(h, "bfsm_collide_partial");
     )
 }
@@ -543,9 +599,11 @@ int bfsm_synchronize(bfsm_handle h) {
 
 void* bfsm_qhat_buffer(bfsm_handle h, size_t* n_elems, int* precision) {
     if (!h) return nullptr;
-    if (n_elems) *n_elems = 2 * h->info.G();
+    if (n_elems) *n_elems = 2 * h->G;
     if (precision) *precision = h->info.precision;
-    return h->p64 ? (void*)h->p64->qhat : (void*)h->p32->qhat;
+    void* q = nullptr;
+    h->with([&](auto& p) { q = (void*)p.qhat; });
+    return q;
 }
 
 int bfsm_fft3d(bfsm_handle h, void* data_dev, int batch, int sign) {
@@ -557,7 +615,9 @@ int bfsm_fft3d(bfsm_handle h, void* data_dev, int batch, int sign) {
         if (!data_dev || batch < 1 || batch > 65535 || (sign != 1 && sign != -1))
             return fail(h, BFSM_ERR_INVALID, "bad fft3d argument (null data, batch outside [1, 65535] or sign not +-1)");
         if (h->p64) h->p64->fft3d((bfsm::cx<double>*)data_dev, batch, sign);
-        else h->p32->fft3d((bfsm::cx<float>*)data_dev, batch, sign);
+        else if (h->p32) h->p32->fft3d((bfsm::cx<float>*)data_dev, batch, sign);
+        else if (h->g64) h->g64->fft3d((bfsm::cx<double>*)data_dev, batch, sign);
+        else h->g32->fft3d((bfsm::cx<float>*)data_dev, batch, sign);
         rc = check_hip(h, "bfsm_fft3d");
         if (rc) return rc;
         return bfsm_synchronize(h);
@@ -600,6 +660,8 @@ int bfsm_destroy(bfsm_handle h) {
     (void)hipDeviceSynchronize();
     if (h->p64) { h->p64->destroy(); delete h->p64; }
     if (h->p32) { h->p32->destroy(); delete h->p32; }
+    if (h->g64) { h->g64->destroy(); delete h->g64; }
+    if (h->g32) { h->g32->destroy(); delete h->g32; }
     h->be.destroy_events();
     delete h;
     return BFSM_OK;

@@ -50,7 +50,8 @@ struct PlanInfo {
     int n2stride = 0;                      // 3*(N/2)^2 + 1
     std::vector<Chunk> chunks;
     int largest_chunk = 0;
-    size_t G() const { return (size_t)N * N * N; }
+    size_t Gtot = 0;                       // grid points when the plan is not a cube of N (size-generic path, N = 0)
+    size_t G() const { return Gtot ? Gtot : (size_t)N * N * N; }
     long long n_dirs() const { return dir_end - dir_begin; }
 };
 
@@ -60,10 +61,26 @@ inline double sincc_ref(double x) {
     return std::sin(x + eps) / (x + eps);
 }
 
-inline int validate_desc(const bfsm_desc& d, std::string& err) {
-    if (d.nvx != d.nvy || d.nvx != d.nvz) { err = "nvx, nvy, nvz must be equal in this build"; return BFSM_ERR_UNSUPPORTED; }
+// Cubic grids of these sizes run on the fused three-kernel pipeline; every other supported grid on the size-generic
+// path of bfsm_generic.hpp.
+inline bool fused_grid(const bfsm_desc& d) {
     const int N = d.nvx;
-    if (N != 16 && N != 32 && N != 64 && N != 128) { err = "grid size must be one of 16, 32, 64, 128"; return BFSM_ERR_UNSUPPORTED; }
+    return d.nvx == d.nvy && d.nvx == d.nvz && (N == 16 || N == 32 || N == 64 || N == 128);
+}
+
+// An axis length the library has a transform for: even (the reference's mode tables need it,
+// FFTWBoltzmannOperator.cpp:50-57), 4 <= n <= 256, prime factors 2, 3, 5.
+inline bool axis_supported(int n) {
+    if (n < 4 || n > 256 || n % 2 != 0) return false;
+    for (int p : {2, 3, 5}) while (n % p == 0) n /= p;
+    return n == 1;
+}
+
+inline int validate_desc(const bfsm_desc& d, std::string& err) {
+    if (!axis_supported(d.nvx) || !axis_supported(d.nvy) || !axis_supported(d.nvz)) {
+        err = "every grid extent must be even, in [4, 256], with prime factors 2, 3, 5 only";
+        return BFSM_ERR_UNSUPPORTED;
+    }
     if (d.precision != BFSM_F64 && d.precision != BFSM_F32) { err = "precision must be BFSM_F64 or BFSM_F32"; return BFSM_ERR_INVALID; }
     if (d.n_gl < 1 || d.n_sph < 1) { err = "n_gl and n_sph must be positive"; return BFSM_ERR_INVALID; }
     if (!d.gl_nodes || !d.gl_wts || !d.sph_wts || !d.sx || !d.sy || !d.sz) { err = "null quadrature array"; return BFSM_ERR_INVALID; }
@@ -74,6 +91,7 @@ inline int validate_desc(const bfsm_desc& d, std::string& err) {
     }
     if (d.max_chunk < 0 || d.max_chunk > 16384) { err = "max_chunk must be in [0, 16384] (it is a grid dimension)"; return BFSM_ERR_INVALID; }
     if (d.max_batch < 0 || d.max_batch > 65535) { err = "max_batch must be in [0, 65535]"; return BFSM_ERR_INVALID; }
+    if (!fused_grid(d) && d.max_chunk > 16383) { err = "max_chunk too large for this grid"; return BFSM_ERR_INVALID; }
     if ((d.flags & BFSM_FLAG_HERMITIAN) && !(d.flags & BFSM_FLAG_EXACT_REDUCTIONS)) {
         err = "BFSM_FLAG_HERMITIAN is an additional exact reduction: set BFSM_FLAG_EXACT_REDUCTIONS as well";
         return BFSM_ERR_INVALID;
@@ -451,6 +469,7 @@ inline double alg_bytes_per_eval(const PlanInfo& p) {
 inline double moved_bytes_per_eval(const PlanInfo& p) {
     const double c = p.precision == BFSM_F64 ? 16.0 : 8.0;
     const double G = (double)p.G(), n = (double)p.n_dirs(), sg = (double)p.segs.size();
+    if (p.N == 0) return (18.0 * n + 27.0) * G * c;   // size-generic path: one pass per axis, pointwise steps fused on the load side
     if (!p.exact_reductions) return (6.0 * n + 2.0 * sg + 9.0) * G * c;
     const double h = p.hermitian ? (double)(p.N / 2 + 1) / p.N : 1.0;
     return (4.0 * n * h + 4.0 * sg + 9.0) * G * c;

@@ -72,8 +72,11 @@ typedef struct bfsm_plan* bfsm_handle;
  * Quadratures/AbstractSphericalQuadratures.hpp:21-42).  All arrays are HOST pointers, copied during create.
  */
 typedef struct bfsm_desc {
-    int nvx, nvy, nvz;        /* velocity grid; this build has kernels for nvx == nvy == nvz in {16,32,64,128},
-                                 in both precisions */
+    int nvx, nvy, nvz;        /* velocity grid: every extent even, in [4, 256], prime factors 2, 3, 5 (the reference
+                                 plans any Nvx x Nvy x Nvz, CUDABoltzmannOperator.cu:86-100).  Cubes of 16, 32, 64,
+                                 128 run on the fused pipeline (6 array passes per direction); every other box on
+                                 the size-generic path (one transform pass per axis), both precisions.  Anything
+                                 else: BFSM_ERR_UNSUPPORTED */
     int n_gl;                 /* Gauss-Legendre points (radial)          */
     int n_sph;                /* spherical quadrature points             */
     const double* gl_nodes;   /* [n_gl]  rho_r on [0,R]                   */
@@ -164,8 +167,9 @@ int bfsm_synchronize(bfsm_handle h);
 /* Batched 3-D complex transform with the library's own kernels (counterpart of the cufftPlanMany plan,
  * CUDABoltzmannOperator.cu:88-100; used by the FFT unit tests that mirror cufft_benchmark.cu:150-207).
  * data_dev: batch * G interleaved complex of the handle's precision, transformed in place, unnormalised.
- * sign -1 = forward: physical [x][y][z] in, spectral-transposed [lx][lz][ly] out (the library's spectral layout);
- * sign +1 = backward: [lx][lz][ly] in, [x][y][z] out.  1 <= batch <= 65535 (one grid dimension). */
+ * sign -1 = forward: physical [x][y][z] in, spectral-transposed [lx][lz][ly] out (the fused pipeline's spectral layout);
+ * sign +1 = backward: [lx][lz][ly] in, [x][y][z] out.  1 <= batch <= 65535 (one grid dimension).
+ * On boxes served by the size-generic path the spectral side is the natural [lx][ly][lz]. */
 int bfsm_fft3d(bfsm_handle h, void* data_dev, int batch, int sign);
 
 int bfsm_get_counters(bfsm_handle h, bfsm_counters* out);

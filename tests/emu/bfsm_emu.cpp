@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../boltzmann-fourier-spectral-method_amd/csrc/bfsm_pipeline.hpp"
+#include "../../boltzmann-fourier-spectral-method_amd/csrc/bfsm_generic.hpp"
 
 namespace emu {
 
@@ -180,6 +181,25 @@ struct EmuBackend {
                 }
     }
 
+    template <bfsm::GK kind, typename T, class P>
+    static void body_gen(void* a, EmuCtx& ctx) {
+        const P& prm = *static_cast<const P*>(a);
+        if constexpr (kind == bfsm::GK::Fft) bfsm::body_gen_fft<T>(prm, ctx);
+        else if constexpr (kind == bfsm::GK::Acc) bfsm::body_gen_acc<T>(prm, ctx);
+        else if constexpr (kind == bfsm::GK::Combine) bfsm::body_gen_combine<T>(prm, ctx);
+    }
+
+    template <bfsm::GK kind, typename T, class P>
+    void launch_gen(int gx, int gy, int threads, size_t lds, const P& prm) {
+        smem.assign(lds ? lds : 16, 0xCD);
+        P copy = prm;
+        for (int by = 0; by < gy; ++by)
+            for (int bx = 0; bx < gx; ++bx) {
+                sched.run_block(threads, bx, by, 0, smem.data(), &body_gen<kind, T, P>, &copy);
+                if (sched.deadlock) failed = true;
+            }
+    }
+
     template <bfsm::K kind, typename T, class P>
     void launch(int gx, int gy, int gz, const P& prm, int N) {
         switch (N) {
@@ -192,8 +212,28 @@ struct EmuBackend {
     }
 };
 
+// size-generic path (bfsm_generic.hpp): same sequence as the library's entry points for such grids
+template <typename T>
+int collide_gen_t(const bfsm_desc* d, const double* f, double* Q, double* qhat_out, int nb, bool with_loss) {
+    EmuBackend be;
+    bfsm::GenericPipeline<T, EmuBackend> p;
+    std::string err;
+    int rc = p.init(*d, &be, err);
+    if (rc) return rc;
+    if (nb < 1 || nb > p.max_batch) return BFSM_ERR_INVALID;
+    for (int i = 0; i < nb; ++i) {
+        p.gain_partial(f + (size_t)i * p.G);
+        if (qhat_out)
+            for (size_t k = 0; k < p.G; ++k) { qhat_out[2 * ((size_t)i * p.G + k)] = (double)p.qhat[k].x; qhat_out[2 * ((size_t)i * p.G + k) + 1] = (double)p.qhat[k].y; }
+        if (Q) p.finish(Q + (size_t)i * p.G, f + (size_t)i * p.G, with_loss);
+    }
+    p.destroy();
+    return be.failed ? 99 : 0;
+}
+
 template <typename T>
 int collide_t(const bfsm_desc* d, const double* f, double* Q, double* qhat_out, int nb, bool with_loss = true) {
+    if (!bfsm::fused_grid(*d)) return collide_gen_t<T>(d, f, Q, qhat_out, nb, with_loss);
     EmuBackend be;
     bfsm::Pipeline<T, EmuBackend> p;
     std::string err;

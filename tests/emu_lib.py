@@ -32,13 +32,14 @@ def make_desc(nv, gl, sph, gamma, b_gamma, L, precision=64, dir_range=(0, 0), ma
     from bfsm import capi
     dp = ctypes.POINTER(ctypes.c_double)
     keep = [np.ascontiguousarray(a, dtype=np.float64) for a in (gl[0], gl[1], sph[3], sph[0], sph[1], sph[2])]
-    d = capi.Desc(nv, nv, nv, len(keep[0]), len(keep[2]), *[a.ctypes.data_as(dp) for a in keep],
+    nx, ny, nz = (nv, nv, nv) if np.isscalar(nv) else (int(v) for v in nv)     # nv: one extent or (nvx, nvy, nvz)
+    d = capi.Desc(nx, ny, nz, len(keep[0]), len(keep[2]), *[a.ctypes.data_as(dp) for a in keep],
                   gamma, b_gamma, L, precision, 0, dir_range[0], dir_range[1], max_chunk, flags, max_batch)
     return d, keep
 
 
 def collide(f, gl, sph, gamma, b_gamma, L, precision=64, dir_range=(0, 0), max_chunk=0, want_Q=True, flags=0):
-    nv = f.shape[0]
+    nv = f.shape[0] if f.shape[0] == f.shape[1] == f.shape[2] else f.shape
     d, keep = make_desc(nv, gl, sph, gamma, b_gamma, L, precision, dir_range, max_chunk, flags)
     f = np.ascontiguousarray(f, dtype=np.float64)
     Q = np.empty_like(f)
@@ -48,8 +49,10 @@ def collide(f, gl, sph, gamma, b_gamma, L, precision=64, dir_range=(0, 0), max_c
                                 qh.ctypes.data_as(dp))
     if rc:
         raise RuntimeError(f"bfsm_emu_collide rc={rc}")
-    qhat_t = qh[..., 0] + 1j * qh[..., 1]            # [lx][lz][ly]
-    return (Q if want_Q else None), np.ascontiguousarray(qhat_t.transpose(0, 2, 1))   # -> [lx][ly][lz]
+    qhat_t = qh[..., 0] + 1j * qh[..., 1]            # fused pipeline: [lx][lz][ly]; size-generic path: natural
+    if np.isscalar(nv) and nv in (16, 32, 64, 128):
+        qhat_t = np.ascontiguousarray(qhat_t.transpose(0, 2, 1))   # -> [lx][ly][lz]
+    return (Q if want_Q else None), qhat_t
 
 
 def fft3d(a, sign, precision=64):

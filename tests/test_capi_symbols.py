@@ -49,9 +49,12 @@ def test_descriptor_validation_errors_are_reported(libpath):
     dp = ctypes.POINTER(ctypes.c_double)
     p = one.ctypes.data_as(dp)
     h = ctypes.c_void_p()
-    bad_n = capi.Desc(48, 48, 48, 4, 4, p, p, p, p, p, p, 0.0, 1.0, 1.0, 64, 0, 0, 0, 0, 0)
-    assert L.bfsm_create(ctypes.byref(bad_n), ctypes.byref(h)) == 2
-    assert b"16, 32, 64, 128" in L.bfsm_last_error(None)
+    # extents the library has no transform for: odd (the reference's mode tables need even sizes), a prime factor other
+    # than 2, 3, 5, or outside [4, 256] -- BFSM_ERR_UNSUPPORTED only beyond the size-generic path
+    for nx, ny, nz in ((15, 16, 16), (16, 14, 16), (16, 16, 22), (512, 16, 16), (2, 16, 16)):
+        bad_n = capi.Desc(nx, ny, nz, 4, 4, p, p, p, p, p, p, 0.0, 1.0, 1.0, 64, 0, 0, 0, 0, 0)
+        assert L.bfsm_create(ctypes.byref(bad_n), ctypes.byref(h)) == 2 and not h.value
+        assert b"grid extent" in L.bfsm_last_error(None)
     bad_prec = capi.Desc(128, 128, 128, 4, 4, p, p, p, p, p, p, 0.0, 1.0, 1.0, 16, 0, 0, 0, 0, 0)
     assert L.bfsm_create(ctypes.byref(bad_prec), ctypes.byref(h)) == 1
     bad_shard = capi.Desc(16, 16, 16, 4, 4, p, p, p, p, p, p, 0.0, 1.0, 1.0, 64, 0, 3, 99, 0, 0)

@@ -123,7 +123,9 @@ def test_plan_chunks_and_segments_cover_shard_once():
 
 def test_plan_rejects_unsupported():
     with pytest.raises(ValueError):
-        E.plan(48, 2, 6)
+        E.plan(50 * 7, 2, 6)                      # 350: beyond 256 and a factor 7
+    with pytest.raises(ValueError):
+        E.plan(14, 2, 6)                          # prime factor 7
     E.plan(128, 2, 6, 64)                # N=128 in fp64 is planned like any other size (split-exchange tiles)
     with pytest.raises(ValueError):
         E.plan(16, 2, 6, 16)             # precision must be 32 or 64
@@ -301,3 +303,29 @@ def test_randomised_plans_against_the_oracle(oracle):
         assert np.abs(qh - ref[1]).max() <= 1e-12 * scale, (case, n_gl, n_sph, flags, max_chunk, lo, hi)
         if want_Q:
             assert np.abs(Q - ref[0]).max() <= 1e-12 * np.abs(ref[0]).max(), (case, n_gl, n_sph, flags, max_chunk)
+
+
+@pytest.mark.parametrize("shape,n_gl,n_sph,prec,tol,kw", [
+    ((8, 4, 12), 3, 12, 64, 1e-12, {}),                      # non-cubic, radix 2 / 4 / 3
+    ((12, 12, 12), 2, 6, 64, 1e-12, {}),                     # cubic but not a fused size (radix 3)
+    ((20, 10, 4), 2, 6, 64, 1e-12, {}),                      # radix 5
+    ((16, 8, 6), 3, 12, 64, 1e-12, {"max_chunk": 5}),        # several chunks of directions
+    ((16, 8, 6), 3, 12, 64, 1e-12, {"dir_range": (7, 29)}),  # a direction shard
+    ((8, 16, 4), 2, 6, 32, 2e-5, {}),                        # single-precision variant
+])
+def test_size_generic_path_matches_oracle(oracle, shape, n_gl, n_sph, prec, tol, kw):
+    """Grids outside the fused pipeline's cubes (csrc/bfsm_generic.hpp: one mixed-radix Stockham pass per axis, pointwise
+    steps fused on the load side) against the oracle, which handles any box like the reference does
+    (FFTWBoltzmannOperator.cpp:64-65 plans Nvx x Nvy x Nvz)."""
+    rng = np.random.default_rng(sum(shape))
+    f = rng.random(shape) + 0.1                              # no symmetry at all
+    gl = oracle.gauss_legendre(n_gl, 0.0, R)
+    sph = oracle.spherical_design(n_sph)
+    L = 11.0
+    rng_ = kw.get("dir_range")
+    Q, qhat = E.collide(f, gl, sph, 0.5, 0.3, L, prec, max_chunk=kw.get("max_chunk", 0), dir_range=rng_ or (0, 0),
+                        want_Q=rng_ is None)
+    Qo, qo = oracle.collide(f, gl, sph, 0.5, 0.3, L, dir_range=rng_, return_qhat=True)
+    assert np.abs(qhat - qo).max() <= tol * np.abs(qo).max()
+    if rng_ is None:
+        assert np.abs(Q - Qo).max() <= tol * np.abs(Qo).max()
