@@ -8,6 +8,7 @@ BFSM_F32 = 32
 BFSM_FLAG_PROFILE = 1
 BFSM_FLAG_EXACT_REDUCTIONS = 2
 BFSM_FLAG_HERMITIAN = 4
+BFSM_FLAG_NO_SMALL_PATH = 8
 KERNEL_NAMES = ("fft_f", "gain_inv", "gain_line", "gain_fwd", "reduce", "tail")
 K_COUNT = len(KERNEL_NAMES)
 

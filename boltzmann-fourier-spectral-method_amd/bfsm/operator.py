@@ -62,6 +62,10 @@ class HIPBoltzmannOperator:
         if on:
             self._flags |= capi.BFSM_FLAG_EXACT_REDUCTIONS | (capi.BFSM_FLAG_HERMITIAN if hermitian else 0)
 
+    def setSmallPath(self, on=True):
+        """N = 16: use (default) or avoid the whole-direction kernels for single evaluations (BFSM_FLAG_NO_SMALL_PATH)."""
+        self._flags = (self._flags & ~capi.BFSM_FLAG_NO_SMALL_PATH) | (0 if on else capi.BFSM_FLAG_NO_SMALL_PATH)
+
     def getBackendName(self):
         return (self._lib or capi.load_library()).bfsm_backend_name().decode()
 

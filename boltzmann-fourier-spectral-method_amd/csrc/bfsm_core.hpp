@@ -996,4 +996,201 @@ BFSM_HD void body_tail_line(const TailLineParams<T>& prm, Ctx& ctx) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Whole-direction kernels for N = 16: the 16^3 grid is 64 KiB of complex doubles, so a workgroup keeps
+// a whole direction in registers + LDS and an evaluation is TWO launches with no HBM intermediates besides one real
+// partial result per workgroup:
+//   small_gain  : every workgroup forms f_hat = FFT(f) itself (32 KiB input, no separate launch to wait for), then for
+//                 each of its directions: phase multiply, both inverse 3-D transforms (A1 and A2 exchanged together),
+//                 product, forward 3-D transform, weighted accumulate (dirw * beta1) in registers; finally it
+//                 inverse-transforms its OWN partial Q_hat (the transform is linear) and stores the real part; one
+//                 workgroup (an extra one while a CU is free, else workgroup 0) transforms beta2 f_hat / G alongside
+//                 and subtracts the loss term from its share;
+//   small_reduce: Q = fixed-order sum of the partial results (replaces the atomics of Kernels.cu:120-121 and the
+//                 combine of Kernels.cu:162-177).
+// 256 threads; thread (i, j) holds a line of 16 points; three layouts of the cube index (a, b, c) -> (a*16 + b)*17 + c:
+//   P: thread (x, y)   holds z = k     S: thread (ly, lz) holds lx = k     M: thread (x | lx, z | lz) holds y | ly = k
+// All exchanges are bank-conflict free for 16-byte elements (consecutive lanes hit consecutive or 17-apart slots).
+// ------------------------------------------------------------------------------------------------------------
+constexpr int SMALL_N = 16;
+constexpr int SMALL_THREADS = 256;
+constexpr int SMALL_CUBE = SMALL_N * SMALL_N * (SMALL_N + 1);       // padded cube, elements
+template <typename T>
+constexpr size_t small_lds_bytes() { return (size_t)2 * SMALL_CUBE * sizeof(cx<T>); }
+
+template <typename T>
+struct SmallGainParams {
+    const double* f;         // [x][y][z]
+    T* part;                 // [workgroup][x][y][z]: Re IFFT of this workgroup's share of Q_gain_hat; workgroup loss_wg
+                             // also subtracts the loss term from its share
+    const T* beta2;          // [n2stride], 1/G folded
+    int loss_wg;             // workgroup that owns the loss term (-1: nobody, the caller's rank does not own it): a gain
+                             // workgroup (it transforms the loss term alongside its own share) or, when the GPU has a
+                             // free CU for it, one extra workgroup after the last gain workgroup (index n_gain_wgs)
+    int n_gain_wgs;
+    const cx<T>* phx;        // [dirs][16]; phx carries the 1/G scale
+    const cx<T>* phy;
+    const cx<T>* phz;
+    const T* dirw;           // [dirs]
+    const T* beta1;          // [n_gl][n2stride]
+    int n2stride;
+    int n_dirs;              // effective directions of this handle's shard
+    int per_wg;              // directions per workgroup (contiguous)
+    long long dir_begin;     // global index of the shard's first effective direction (radial node = index / sph_eff)
+    int sph_eff;
+    int sum_first;           // exact-reduction mode: sum the products of a radial run, transform forward once
+};
+
+template <typename T>
+struct SmallReduceParams {
+    const T* part;           // [n_part][G] real
+    double* Q;               // [x][y][z]
+    int n_part;
+};
+
+enum : int { SMALL_P = 0, SMALL_M = 1, SMALL_S = 2 };
+template <int LAYOUT>
+BFSM_HD int small_slot(int i, int j, int k) {
+    if (LAYOUT == SMALL_P) return (i * 16 + j) * 17 + k;      // (x, y, z = k)
+    if (LAYOUT == SMALL_M) return (i * 16 + k) * 17 + j;      // (x, y = k, z)
+    return (k * 16 + i) * 17 + j;                             // (x = k, y, z)
+}
+
+// re-distribute NA arrays from layout FROM to layout TO through LDS (one buffer of SMALL_CUBE elements per array)
+template <int FROM, int TO, int NA, typename T, class Ctx>
+BFSM_HD void small_exchange(cx<T> (*v)[16], cx<T>* lds, int i, int j, Ctx& ctx) {
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) ctx.lds_st(lds + a * SMALL_CUBE + small_slot<FROM>(i, j, k), v[a][k]);
+    ctx.sync();
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[a][k] = ctx.lds_ld(lds + a * SMALL_CUBE + small_slot<TO>(i, j, k));
+    ctx.sync();
+}
+
+// 3-D transforms of NA arrays held by the workgroup.  Forward: layout P in, S out.  Backward: S in, P out.
+template <int NA, typename T, class Ctx>
+BFSM_HD void small_fft_fwd(cx<T> (*v)[16], cx<T>* lds, int i, int j, Ctx& ctx) {
+#pragma unroll
+    for (int a = 0; a < NA; ++a) SmallDft<16, -1, T>::run(v[a]);       // along z
+    small_exchange<SMALL_P, SMALL_M, NA, T>(v, lds, i, j, ctx);
+#pragma unroll
+    for (int a = 0; a < NA; ++a) SmallDft<16, -1, T>::run(v[a]);       // along y
+    small_exchange<SMALL_M, SMALL_S, NA, T>(v, lds, i, j, ctx);
+#pragma unroll
+    for (int a = 0; a < NA; ++a) SmallDft<16, -1, T>::run(v[a]);       // along x
+}
+template <int NA, typename T, class Ctx>
+BFSM_HD void small_fft_inv(cx<T> (*v)[16], cx<T>* lds, int i, int j, Ctx& ctx) {
+#pragma unroll
+    for (int a = 0; a < NA; ++a) SmallDft<16, +1, T>::run(v[a]);       // along lx
+    small_exchange<SMALL_S, SMALL_M, NA, T>(v, lds, i, j, ctx);
+#pragma unroll
+    for (int a = 0; a < NA; ++a) SmallDft<16, +1, T>::run(v[a]);       // along ly
+    small_exchange<SMALL_M, SMALL_P, NA, T>(v, lds, i, j, ctx);
+#pragma unroll
+    for (int a = 0; a < NA; ++a) SmallDft<16, +1, T>::run(v[a]);       // along lz
+}
+
+// grid.x = workgroups; each owns per_wg consecutive directions of the shard
+template <typename T, class Ctx>
+BFSM_HD void body_small_gain(const SmallGainParams<T>& prm, Ctx& ctx) {
+    const int tid = ctx.tid(), i = tid >> 4, j = tid & 15;
+    cx<T>* lds = ctx.template lds<cx<T>>();
+    // f_hat in layout S, kept in registers for every direction of this workgroup
+    cx<T> fh[1][16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) fh[0][k] = {(T)prm.f[(i * 16 + j) * 16 + k], (T)0};     // layout P: (x = i, y = j, z = k)
+    small_fft_fwd<1, T>(fh, lds, i, j, ctx);                                             // layout S: (lx = k, ly = i, lz = j)
+    const int my = mode_of(i, 16), mz = mode_of(j, 16);
+    T* dst = prm.part + (size_t)ctx.bx() * 4096;
+    cx<T> acc[16], psum[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { acc[k] = {(T)0, (T)0}; psum[k] = {(T)0, (T)0}; }
+    const int d0 = ctx.bx() * prm.per_wg;
+    int d1 = d0 + prm.per_wg;
+    if (d1 > prm.n_dirs) d1 = prm.n_dirs;
+    if (ctx.bx() >= prm.n_gain_wgs) d1 = d0;                   // the extra workgroup owns no directions
+    for (int d = d0; d < d1; ++d) {
+        const int r = (int)((prm.dir_begin + d) / prm.sph_eff);
+        // e^{+-i theta} / G = phx[lx] * (phy[ly] * phz[lz])   (compute_alpha_times_f_hat, Kernels.cu:21-59)
+        const cx<T> c0 = cmul(prm.phy[(size_t)d * 16 + i], prm.phz[(size_t)d * 16 + j]);
+        cx<T> a[2][16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const cx<T> ph = cmul(c0, ctx.ldc(prm.phx + (size_t)d * 16 + k));
+            a[0][k] = cmul(fh[0][k], ph);
+            a[1][k] = cmulc(fh[0][k], ph);
+        }
+        small_fft_inv<2, T>(a, lds, i, j, ctx);                 // A1, A2 in layout P
+        const T w = prm.dirw[d];
+        const bool run_ends = !prm.sum_first || d + 1 == d1 || (int)((prm.dir_begin + d + 1) / prm.sph_eff) != r;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {                          // hadamard_product (Kernels.cu:62-74), weighted
+            const cx<T> pr = cmul(a[0][k], a[1][k]);
+            psum[k].x += w * pr.x;
+            psum[k].y += w * pr.y;
+        }
+        if (run_ends) {                                         // workgroup-uniform
+            cx<T> (*ps)[16] = reinterpret_cast<cx<T> (*)[16]>(psum);
+            small_fft_fwd<1, T>(ps, lds, i, j, ctx);            // layout S
+            const T* b1 = prm.beta1 + (size_t)r * prm.n2stride;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int mx = mode_of(k, 16);
+                const T b = b1[mx * mx + my * my + mz * mz];
+                acc[k].x += b * psum[k].x;
+                acc[k].y += b * psum[k].y;
+                psum[k] = {(T)0, (T)0};
+            }
+        }
+    }
+    // the inverse transform is linear: this workgroup's share goes back to physical space here, the reduce sums reals
+    if (ctx.bx() != prm.loss_wg) {
+        cx<T> (*ac)[16] = reinterpret_cast<cx<T> (*)[16]>(acc);
+        small_fft_inv<1, T>(ac, lds, i, j, ctx);                                         // layout P: (x = i, y = j, z = k)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) dst[(i * 16 + j) * 16 + k] = acc[k].x;
+    } else {
+        // the owner of the loss term transforms beta2 * f_hat / G alongside (compute_beta2_times_f_hat, Kernels.cu:126-159;
+        // inverse transforms cu:203-212) and combines: share - Re(loss) * f   (compute_Q_total, Kernels.cu:162-177)
+        cx<T> v[2][16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int mx = mode_of(k, 16);
+            const T b2 = prm.beta2[mx * mx + my * my + mz * mz];
+            v[0][k] = acc[k];
+            v[1][k] = {b2 * fh[0][k].x, b2 * fh[0][k].y};
+        }
+        small_fft_inv<2, T>(v, lds, i, j, ctx);
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            dst[(i * 16 + j) * 16 + k] = (T)((double)v[0][k].x - (double)v[1][k].x * prm.f[(i * 16 + j) * 16 + k]);
+    }
+}
+
+// grid.x = 256 workgroups of 256 threads: workgroup = 16 grid points, 16 groups of partial results; the order of the
+// additions is fixed (group-local runs first, then the groups in index order)
+template <typename T, class Ctx>
+BFSM_HD void body_small_reduce(const SmallReduceParams<T>& prm, Ctx& ctx) {
+    const int tid = ctx.tid(), g = tid >> 4, pt = tid & 15;
+    const size_t idx = (size_t)ctx.bx() * 16 + pt;
+    double* lds = ctx.template lds<double>();
+    const int per = (prm.n_part + 15) / 16;
+    double q = 0;
+    for (int w = g * per; w < (g + 1) * per && w < prm.n_part; ++w) q += (double)prm.part[(size_t)w * 4096 + idx];
+    lds[g * 16 + pt] = q;
+    ctx.sync();
+    if (g == 0) {
+        double s = lds[pt];
+#pragma unroll
+        for (int gg = 1; gg < 16; ++gg) s += lds[gg * 16 + pt];
+        prm.Q[idx] = s;
+    }
+}
+
 }  // namespace bfsm

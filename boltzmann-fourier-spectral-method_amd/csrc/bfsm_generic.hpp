@@ -404,6 +404,8 @@ struct GenericPipeline {
 
     int axis_len(int ax) const { return ax == 0 ? nx : (ax == 1 ? ny : nz); }
     bool fuse_reduce() const { return false; }
+    bool small_path(int) const { return false; }
+    void collide_small(double*, const double*, bool) {}
 
     // one axis pass over `batch` arrays; member b of in / out sits at + b * in_bstride / + b * out_bstride.  A pass may
     // run in place: every workgroup reads its whole block of lines into LDS before it stores the same block.

@@ -230,6 +230,15 @@ __global__ void __launch_bounds__(GEN_THREADS) bfsm_gen_kernel(const P prm) {
     else if constexpr (kind == GK::Combine) body_gen_combine<T>(prm, ctx);
 }
 
+// N = 16 whole-direction kernels: 256 threads, two padded cubes of LDS
+template <SK kind, typename T, class P>
+__global__ void __launch_bounds__(SMALL_THREADS) bfsm_small_kernel(const P prm) {
+    extern __shared__ __align__(16) unsigned char bfsm_smem[];
+    DevCtx ctx{bfsm_smem};
+    if constexpr (kind == SK::Gain) body_small_gain<T>(prm, ctx);
+    else if constexpr (kind == SK::Reduce) body_small_reduce<T>(prm, ctx);
+}
+
 // ---- HIP backend -----------------------------------------------------------------------------------------------
 struct HipBackend {
     hipStream_t stream = nullptr;
@@ -293,6 +302,33 @@ struct HipBackend {
         void* args[] = {const_cast<void*>(static_cast<const void*>(&prm))};
         BFSM_NOTE(hipLaunchKernel(reinterpret_cast<const void*>(fn), dim3((unsigned)gx, (unsigned)gy, (unsigned)gz),
                                   dim3(threads, 1, 1), args, lds, stream));
+        if (timed) { BFSM_NOTE(hipEventRecord(rec.e1, stream)); recs.push_back(rec); }
+        pend_kind = -1;
+    }
+
+    template <SK kind, typename T, class P>
+    void launch_small(int gx, const P& prm) {
+        launch_any(reinterpret_cast<const void*>(bfsm_small_kernel<kind, T, P>), gx, 1, SMALL_THREADS,
+                   kind == SK::Reduce ? 256 * sizeof(double) : small_lds_bytes<T>(), &prm,
+                   small_attr_done[(int)kind][sizeof(T) == 8]);
+    }
+    std::atomic<unsigned long long> small_attr_done[2][2] = {};
+
+    // common tail of the size-independent launchers: large-LDS opt-in once per device, events, launch status
+    void launch_any(const void* fn, int gx, int gy, int threads, size_t lds, const void* prm, std::atomic<unsigned long long>& done) {
+        if (gx <= 0 || gy <= 0) return;
+        if (lds > 48 * 1024) {
+            const unsigned long long bit = 1ull << (device & 63);
+            if (!(done.load(std::memory_order_relaxed) & bit)) {
+                BFSM_NOTE(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                done.fetch_or(bit, std::memory_order_relaxed);
+            }
+        }
+        Rec rec{pend_kind, pend_bytes, nullptr, nullptr};
+        const bool timed = profile && pend_kind >= 0;
+        if (timed) { rec.e0 = next_event(); rec.e1 = next_event(); BFSM_NOTE(hipEventRecord(rec.e0, stream)); }
+        void* args[] = {const_cast<void*>(prm)};
+        BFSM_NOTE(hipLaunchKernel(fn, dim3((unsigned)gx, (unsigned)gy, 1), dim3((unsigned)threads, 1, 1), args, lds, stream));
         if (timed) { BFSM_NOTE(hipEventRecord(rec.e1, stream)); recs.push_back(rec); }
         pend_kind = -1;
     }
@@ -573,7 +609,12 @@ int bfsm_collide_partial_async(bfsm_handle h, double* Q_dev, const double* f_dev
         if (!f_dev || !Q_dev) return fail(h, BFSM_ERR_INVALID, "null f or Q");
         h->be.begin_eval();
         // gain kernels, then the tail; with few slabs the reduce is fused into its first kernel (qhat is not written then)
-        h->with([&](auto& p) { const bool fu = p.fuse_reduce(); p.gain_partial(f_dev, 1, !fu); p.finish(Q_dev, f_dev, with_loss != 0, 1, fu); });
+        h->with([&](auto& p) {
+            if (p.small_path(1)) { p.collide_small(Q_dev, f_dev, with_loss != 0); return; }   // N = 16: whole-direction kernels
+            const bool fu = p.fuse_reduce();
+            p.gain_partial(f_dev, 1, !fu);
+            p.finish(Q_dev, f_dev, with_loss != 0, 1, fu);
+        });
         return check_hip(h, "bfsm_collide_partial");
     )
 }

@@ -250,6 +250,9 @@ HostTables<T> build_tables(const bfsm_desc& d, const PlanInfo& p) {
     return t;
 }
 
+// Kernels of the N = 16 whole-direction path (bfsm_core.hpp, "small_*").
+enum class SK { Gain, Reduce };
+
 // Kernel identifiers the backend dispatches on.
 enum class K { TileFwdReal, LineFwd, LineInv, TileFwd, TileInv, GainInv, GainLine, GainFwd, Reduce, TailInv, TailLine, GainLineAcc,
                NyqRows, GainLineAccH };
@@ -290,6 +293,9 @@ struct Pipeline {
     T* ones = nullptr;
     cx<T>* rnyq = nullptr;        // Hermitian mode: Nyquist rows [slot][sign][kind][N/2-1][N]
     size_t slab_count = 0;
+    // N = 16 whole-direction path: one partial Q_hat per workgroup
+    T* small_part = nullptr;      // [small_wgs + 1][G] real partial results
+    int small_wgs = 0, small_per = 0;
 
     template <typename U>
     bool dev_copy(U*& dst, const std::vector<U>& src) {
@@ -335,12 +341,40 @@ struct Pipeline {
             ok = ok && (pseg = (cx<T>*)be->alloc(nb * nslab * G * sizeof(cx<T>)));
             ok = ok && dev_copy(segs_unit, unit) && dev_copy(ones, one);
         }
+        if (ok && plan.N == SMALL_N && !(d.flags & BFSM_FLAG_NO_SMALL_PATH) && plan.n_dirs() > 0 && max_batch == 1) {
+            // a whole direction fits one workgroup: single evaluations take the three-launch path of collide_small
+            // (handles created for batches keep one set of kernels: a single evaluation on them is bitwise a batch member)
+            const long long nd = plan.n_dirs();
+            const long long wg = nd < 256 ? nd : 256;
+            small_per = (int)((nd + wg - 1) / wg);
+            small_wgs = (int)((nd + small_per - 1) / small_per);
+            ok = ok && (small_part = (T*)be->alloc((size_t)(small_wgs + 1) * G * sizeof(T)));
+        }
         if (!ok) { err = "device allocation failed"; return BFSM_ERR_NOMEM; }
         return BFSM_OK;
     }
 
+    // Whole evaluation on the N = 16 path (two launches, see bfsm_core.hpp); Q = gain [- loss]
+    bool small_path(int nb) const { return small_part != nullptr && nb == 1; }
+    void collide_small(double* Q_dev, const double* f_dev, bool with_loss) {
+        const double Gc = (double)plan.G() * cbytes();
+        // the loss term: one more workgroup while the gain workgroups leave a CU free (one workgroup per CU: 136 KiB of
+        // LDS), otherwise workgroup 0 carries it next to its own share
+        const bool extra = with_loss && small_wgs < 256;
+        SmallGainParams<T> kg{f_dev, small_part, beta2, with_loss ? (extra ? small_wgs : 0) : -1, small_wgs, phx, phy, phz, dirw,
+                              beta1, plan.n2stride, (int)plan.n_dirs(), small_per, plan.dir_begin, plan.sph_eff,
+                              plan.exact_reductions ? 1 : 0};
+        const int n_part = small_wgs + (extra ? 1 : 0);
+        be->mark(BFSM_K_GAIN_LINE, 0.5 * n_part * Gc);
+        be->template launch_small<SK::Gain, T>(n_part, kg);
+        SmallReduceParams<T> kr{small_part, Q_dev, n_part};
+        be->mark(BFSM_K_REDUCE, 0.5 * (n_part + 1.0) * Gc);
+        be->template launch_small<SK::Reduce, T>((int)(plan.G() / 16), kr);
+    }
+
     void destroy() {
         if (!be) return;
+        if (small_part) { be->release(small_part); small_part = nullptr; }
         void* ptrs[] = {fhat, tg, tl, qhat, a1, a2, slab, tw, phx, phy, phz, dirw, beta1, beta2, segs, pseg, segs_unit, ones, rnyq};
         for (void* p : ptrs) if (p) be->release(p);
         fhat = tg = tl = qhat = a1 = a2 = slab = tw = phx = phy = phz = nullptr;

@@ -60,7 +60,11 @@ enum {
      * half-transformed arrays satisfy A'[-lx] = conj A'[lx] up to the three Nyquist planes; only the planes
      * lx = 0 .. N/2 are computed and stored, the rest is rebuilt by conjugation plus exact rank-one Nyquist terms
      * (the r2c / c2r saving the reference lists as future work, CUDABoltzmannOperator.cu:36). */
-    BFSM_FLAG_HERMITIAN = 4
+    BFSM_FLAG_HERMITIAN = 4,
+    /* N = 16 only: do not use the whole-direction kernels (a direction kept in one workgroup's LDS, three launches
+     * per evaluation) for single evaluations; the plane-tile pipeline of the larger grids is used instead.  Same
+     * results up to rounding order; for comparisons and tests. */
+    BFSM_FLAG_NO_SMALL_PATH = 8
 };
 
 typedef struct bfsm_plan* bfsm_handle;

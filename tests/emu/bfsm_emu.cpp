@@ -181,6 +181,23 @@ struct EmuBackend {
                 }
     }
 
+    template <bfsm::SK kind, typename T, class P>
+    static void body_small(void* a, EmuCtx& ctx) {
+        const P& prm = *static_cast<const P*>(a);
+        if constexpr (kind == bfsm::SK::Gain) bfsm::body_small_gain<T>(prm, ctx);
+        else if constexpr (kind == bfsm::SK::Reduce) bfsm::body_small_reduce<T>(prm, ctx);
+    }
+
+    template <bfsm::SK kind, typename T, class P>
+    void launch_small(int gx, const P& prm) {
+        smem.assign(bfsm::small_lds_bytes<T>(), 0xCD);
+        P copy = prm;
+        for (int bx = 0; bx < gx; ++bx) {
+            sched.run_block(bfsm::SMALL_THREADS, bx, 0, 0, smem.data(), &body_small<kind, T, P>, &copy);
+            if (sched.deadlock) failed = true;
+        }
+    }
+
     template <bfsm::GK kind, typename T, class P>
     static void body_gen(void* a, EmuCtx& ctx) {
         const P& prm = *static_cast<const P*>(a);
@@ -243,6 +260,11 @@ int collide_t(const bfsm_desc* d, const double* f, double* Q, double* qhat_out, 
     // qhat requested: the two-call sequence (bfsm_gain_partial, bfsm_finish); otherwise the fused sequence of
     // bfsm_collide / bfsm_collide_batch / bfsm_collide_partial_async (slab reduce inside the first tail kernel)
     const bool fused = qhat_out == nullptr;   // (the library additionally fuses only shards with few slabs)
+    if (fused && Q && p.small_path(nb)) {     // N = 16: the whole-direction kernels, as bfsm_collide_partial_async
+        p.collide_small(Q, f, with_loss);
+        p.destroy();
+        return be.failed ? 99 : 0;
+    }
     p.gain_partial(f, nb, !fused);
     if (qhat_out) {
         const size_t G = p.plan.G() * (size_t)nb;

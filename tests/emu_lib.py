@@ -170,3 +170,23 @@ class EmuOperatorFused(EmuOperator):
         if rc:
             raise RuntimeError(f"bfsm_emu_collide_partial rc={rc}")
         Q.copy_(torch.from_numpy(out))
+
+
+def collide_partial(f, gl, sph, gamma, b_gamma, L, precision=64, dir_range=(0, 0), with_loss=True, flags=0, max_chunk=0):
+    """Emulated bfsm_collide_partial_async (what bfsm_collide runs): at N = 16 the whole-direction kernels unless
+    flags has BFSM_FLAG_NO_SMALL_PATH, otherwise the fused plane-tile sequence."""
+    nv = f.shape[0] if f.shape[0] == f.shape[1] == f.shape[2] else f.shape
+    d, keep = make_desc(nv, gl, sph, gamma, b_gamma, L, precision, dir_range, max_chunk, flags)
+    f = np.ascontiguousarray(f, dtype=np.float64)
+    Q = np.empty_like(f)
+    dp = ctypes.POINTER(ctypes.c_double)
+    L_ = lib()
+    if not hasattr(L_.bfsm_emu_collide_partial, "_typed"):
+        from bfsm import capi
+        L_.bfsm_emu_collide_partial.argtypes = [ctypes.POINTER(capi.Desc), dp, dp, ctypes.c_int]
+        L_.bfsm_emu_collide_partial.restype = ctypes.c_int
+        L_.bfsm_emu_collide_partial._typed = True
+    rc = L_.bfsm_emu_collide_partial(ctypes.byref(d), f.ctypes.data_as(dp), Q.ctypes.data_as(dp), 1 if with_loss else 0)
+    if rc:
+        raise RuntimeError(f"bfsm_emu_collide_partial rc={rc}")
+    return Q

@@ -329,3 +329,31 @@ def test_size_generic_path_matches_oracle(oracle, shape, n_gl, n_sph, prec, tol,
     assert np.abs(qhat - qo).max() <= tol * np.abs(qo).max()
     if rng_ is None:
         assert np.abs(Q - Qo).max() <= tol * np.abs(Qo).max()
+
+
+@pytest.mark.parametrize("n_gl,n_sph,flags,rng,prec,tol", [
+    (3, 12, 0, (0, 0), 64, 1e-12),          # faithful: one forward transform per direction
+    (8, 32, 0, (0, 0), 64, 1e-12),          # config 1: 256 directions, one per workgroup
+    (40, 12, 0, (0, 0), 64, 1e-12),         # 480 directions: two per workgroup, runs cross radial nodes
+    (3, 12, 2, (0, 0), 64, 1e-12),          # exact reductions: antipodal pairs merged, products summed per radial run
+    (3, 12, 6, (0, 0), 64, 1e-12),          # + hermitian flag (same kernels on this path)
+    (3, 12, 0, (5, 29), 64, 1e-12),         # a direction shard
+    (2, 6, 0, (0, 0), 32, 2e-5),            # single precision
+])
+def test_whole_direction_kernels_n16(oracle, n_gl, n_sph, flags, rng, prec, tol):
+    """N = 16: a direction lives in one workgroup's registers + LDS (small_gain / small_reduce / small_tail, three
+    launches per evaluation) -- the sequence bfsm_collide runs at this size -- against the oracle."""
+    f, _, L, _ = oracle.bkw(16)
+    f = oracle.perturbed_input(f)
+    gl = oracle.gauss_legendre(n_gl, 0.0, R)
+    sph = oracle.spherical_design(n_sph)
+    got = E.collide_partial(f, gl, sph, GAMMA, B_GAMMA, L, prec, dir_range=rng, flags=flags)
+    ref = oracle.collide(f, gl, sph, GAMMA, B_GAMMA, L, dir_range=rng if rng != (0, 0) else None)
+    assert np.abs(got - ref).max() <= tol * np.abs(ref).max()
+    # the same call with the whole-direction kernels switched off takes the plane-tile pipeline: same answer
+    other = E.collide_partial(f, gl, sph, GAMMA, B_GAMMA, L, prec, dir_range=rng, flags=flags | 8)
+    assert np.abs(other - ref).max() <= tol * np.abs(ref).max()
+    if rng != (0, 0):       # a rank that does not own the loss term
+        g = E.collide_partial(f, gl, sph, GAMMA, B_GAMMA, L, prec, dir_range=rng, with_loss=False, flags=flags)
+        g2 = E.collide_partial(f, gl, sph, GAMMA, B_GAMMA, L, prec, dir_range=rng, with_loss=False, flags=flags | 8)
+        assert np.abs(g - g2).max() <= tol * np.abs(ref).max()

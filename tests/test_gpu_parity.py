@@ -25,7 +25,7 @@ def torch_cuda():
 
 
 def _make(bfsm, nv, n_gl, n_sph, precision=64, shard=None, max_chunk=0, profile=False, exact=False, gamma=None,
-          b_gamma=None, max_batch=0, hermitian=False):
+          b_gamma=None, max_batch=0, hermitian=False, small_path=True):
     c = dict(bfsm.reference_constants())
     if gamma is not None:
         c["gamma"], c["b_gamma"] = gamma, b_gamma
@@ -40,6 +40,7 @@ def _make(bfsm, nv, n_gl, n_sph, precision=64, shard=None, max_chunk=0, profile=
     op.setProfiling(profile)
     op.setExactReductions(exact or hermitian, hermitian=hermitian)
     op.setMaxBatch(max_batch)
+    op.setSmallPath(small_path)
     op.initialize()
     return op
 
@@ -653,11 +654,12 @@ def test_cpp_fft_benchmark_driver(torch_cuda):
 @pytest.mark.parametrize("nv,n_gl,n_sph,exact", [(16, 8, 32, False), (64, 2, 12, False), (32, 4, 12, True)])
 def test_fused_collide_is_bitwise_the_two_call_sequence(torch_cuda, nv, n_gl, n_sph, exact):
     """bfsm_collide and bfsm_collide_partial_async (slab reduce fused into the tail) against bfsm_gain_partial +
-    bfsm_finish / bfsm_finish_partial on the same handle: same bits."""
+    bfsm_finish / bfsm_finish_partial on the same handle: same bits.  (N = 16: with the whole-direction kernels switched
+    off -- they are a different summation order, compared with the oracle in their own test.)"""
     import bfsm
     torch = torch_cuda
     f = torch.from_numpy(bfsm.perturbed_input(bfsm.bkw_solution(nv)[0])).cuda()
-    op = _make(bfsm, nv, n_gl, n_sph, exact=exact, hermitian=exact, max_chunk=7)
+    op = _make(bfsm, nv, n_gl, n_sph, exact=exact, hermitian=exact, max_chunk=7, small_path=False)
     Qa, Qb = torch.empty_like(f), torch.empty_like(f)
     op(Qa, f)                                   # fused
     op.gainPartial(f)
@@ -666,7 +668,7 @@ def test_fused_collide_is_bitwise_the_two_call_sequence(torch_cuda, nv, n_gl, n_
     assert torch.equal(Qa, Qb)
     op.destroy()
     B = n_gl * n_sph
-    shard = _make(bfsm, nv, n_gl, n_sph, shard=(B // 3, B), exact=exact, hermitian=exact)
+    shard = _make(bfsm, nv, n_gl, n_sph, shard=(B // 3, B), exact=exact, hermitian=exact, small_path=False)
     for with_loss in (False, True):
         shard.collidePartial(Qa, f, with_loss)
         shard.gainPartial(f)
@@ -871,3 +873,36 @@ def test_cpp_driver_on_a_size_with_factor_three(torch_cuda):
     assert out.returncode == 0, out.stderr[-2000:]
     l2 = float(re.search(r"L2 error: (\S+)", out.stdout).group(1))
     assert GOLD["published"][2]["L2"] < l2 < GOLD["published"][0]["L2"]
+
+
+@pytest.mark.parametrize("mode", ["faithful", "exact", "hermitian"])
+@pytest.mark.parametrize("n_gl,n_sph,prec", [(8, 32, 64), (40, 12, 64), (3, 6, 64), (8, 32, 32)])
+def test_n16_whole_direction_kernels_and_tile_pipeline_agree_with_oracle(torch_cuda, oracle, n_gl, n_sph, prec, mode):
+    """N = 16 single evaluations run on the whole-direction kernels (three launches); BFSM_FLAG_NO_SMALL_PATH sends the
+    same call through the plane-tile pipeline.  Both against the oracle, all three modes, plus a shard without loss."""
+    import bfsm
+    torch = torch_cuda
+    f_h = bfsm.perturbed_input(bfsm.bkw_solution(16)[0])
+    ref = _oracle(oracle, f_h, n_gl, n_sph)
+    # fp32 at N = 16: Q is the small difference of gain and loss (the grid does not resolve f), so rounding relative to
+    # max|Q| is amplified: measured 1.3e-5 (whole-direction kernels) / 8.6e-6 (tile pipeline) on config 1
+    tol = TOL64 if prec == 64 else 5e-5
+    for small in (True, False):
+        op = _make(bfsm, 16, n_gl, n_sph, prec, exact=(mode != "faithful"), hermitian=(mode == "hermitian"), small_path=small)
+        got = _collide(torch, op, f_h)
+        q2 = _collide(torch, op, f_h)
+        op.destroy()
+        assert np.array_equal(got, q2)                                   # deterministic (no atomics)
+        assert np.abs(got - ref).max() <= tol * np.abs(ref).max(), small
+    B = n_gl * n_sph
+    f = torch.from_numpy(f_h).cuda()
+    parts = []
+    for r in range(2):
+        op = _make(bfsm, 16, n_gl, n_sph, prec, shard=bfsm.shard_range(B, r, 2), exact=(mode != "faithful"),
+                   hermitian=(mode == "hermitian"))
+        Q = torch.empty_like(f)
+        op.collidePartial(Q, f, r == 0)
+        torch.cuda.synchronize()
+        parts.append(Q.cpu().numpy())
+        op.destroy()
+    assert np.abs(parts[0] + parts[1] - ref).max() <= tol * np.abs(ref).max()
