@@ -72,20 +72,10 @@ struct DevCtx {
     }
     template <class T>
     __device__ __forceinline__ void lds_st(cx<T>* p, cx<T> v) const { *p = v; }
-    // scalar element of the split (real / imaginary) exchange: the same, for one 8-byte double
+    // scalar element of the split (real / imaginary) exchange (fp64, N = 128): left to the compiler's pairing, which
+    // measured faster than unpaired reads in that path
     template <class T>
-    __device__ __forceinline__ T lds_ld_s(const T* p) const {
-#ifdef BFSM_LDS_UNPAIRED_SPLIT     // measured slower than the compiler's pairing in this (fp64, N = 128) path
-        if constexpr (sizeof(T) == 8) {
-            typedef const volatile T __attribute__((address_space(3))) * lptr;
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Wold-style-cast"
-            return *(lptr)(p);
-#pragma clang diagnostic pop
-        }
-#endif
-        return *p;
-    }
+    __device__ __forceinline__ T lds_ld_s(const T* p) const { return *p; }
     // Once-touched scratch (A1', A2', P'): nontemporal accesses keep the streams from evicting the small hot set
     // (f_hat planes, tables) out of L2.
     template <class T>
