@@ -14,7 +14,7 @@ K_COUNT = len(KERNEL_NAMES)
 
 # every symbol include/bfsm.h declares (checked by tests/test_capi_symbols.py)
 EXPORTED_SYMBOLS = (
-    "bfsm_create", "bfsm_collide", "bfsm_collide_async", "bfsm_collide_batch", "bfsm_collide_batch_async", "bfsm_gain_partial", "bfsm_finish", "bfsm_finish_partial", "bfsm_collide_partial_async",
+    "bfsm_create", "bfsm_collide", "bfsm_collide_async", "bfsm_collide_batch", "bfsm_collide_batch_async", "bfsm_collide_batch_partial_async", "bfsm_gain_partial", "bfsm_finish", "bfsm_finish_partial", "bfsm_collide_partial_async",
     "bfsm_qhat_buffer",
     "bfsm_synchronize", "bfsm_fft3d", "bfsm_get_counters", "bfsm_destroy", "bfsm_last_error", "bfsm_backend_name",
     "bfsm_version",
@@ -85,6 +85,8 @@ def load_library(path=None):
     L.bfsm_collide_batch.restype = ctypes.c_int
     L.bfsm_collide_batch_async.argtypes = [vp, vp, vp, ctypes.c_int, vp]
     L.bfsm_collide_batch_async.restype = ctypes.c_int
+    L.bfsm_collide_batch_partial_async.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, vp]
+    L.bfsm_collide_batch_partial_async.restype = ctypes.c_int
     L.bfsm_gain_partial.argtypes = [vp, vp, vp]
     L.bfsm_gain_partial.restype = ctypes.c_int
     L.bfsm_finish.argtypes = [vp, vp, vp, vp]

@@ -126,6 +126,16 @@ class HIPBoltzmannOperator:
             self._check(self._lib.bfsm_collide_batch_async(self._h, _ptr(Q), _ptr(f_in), int(n_batch),
                                                            ctypes.c_void_p(stream)))
 
+    def collideBatchPartial(self, Q, f_in, n_batch, with_loss, stream=0):
+        """Batch x direction shard: member i of Q = this shard's partial result for member i [- its loss term]; the
+        caller sums Q over the ranks with one collective for the whole batch."""
+        G = self.Nvx * self.Nvy * self.Nvz
+        for t in (f_in, Q):
+            if not (t.is_cuda and t.element_size() == 8 and t.is_contiguous() and t.numel() == n_batch * G):
+                raise ValueError("f and Q must be contiguous float64 CUDA tensors with n_batch*Nvx*Nvy*Nvz elements")
+        self._check(self._lib.bfsm_collide_batch_partial_async(self._h, _ptr(Q), _ptr(f_in), int(n_batch),
+                                                               1 if with_loss else 0, ctypes.c_void_p(stream)))
+
     def gainPartial(self, f_in, stream=0):
         self._require(f_in)
         self._check(self._lib.bfsm_gain_partial(self._h, _ptr(f_in), ctypes.c_void_p(stream)))

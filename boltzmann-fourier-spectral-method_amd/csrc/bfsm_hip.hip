@@ -554,14 +554,13 @@ int bfsm_finish_partial(bfsm_handle h, double* Q_dev, const double* f_dev, int w
     )
 }
 
-int bfsm_collide_batch_async(bfsm_handle h, double* Q_dev, const double* f_dev, int n_batch, void* stream) {
+int bfsm_collide_batch_partial_async(bfsm_handle h, double* Q_dev, const double* f_dev, int n_batch, int with_loss, void* stream) {
     if (!h) return BFSM_ERR_INVALID;
     BFSM_GUARDED(h,
         DeviceGuard g(h->desc.device);
         int rc = enter(h, g, stream);
         if (rc) return rc;
         if (!f_dev || !Q_dev) return fail(h, BFSM_ERR_INVALID, "null f or Q");
-        if (!h->full_shard) return fail(h, BFSM_ERR_INVALID, "batched evaluation needs a handle that owns all directions");
         int cap = 1;
         h->with([&](auto& p) { cap = p.max_batch; });
         if (n_batch < 1 || n_batch > cap)
@@ -569,12 +568,18 @@ int bfsm_collide_batch_async(bfsm_handle h, double* Q_dev, const double* f_dev, 
         h->be.begin_eval();
         if (h->g64 || h->g32) {      // the size-generic path evaluates the members one after the other
             for (int i = 0; i < n_batch; ++i)
-                h->with([&](auto& p) { p.gain_partial(f_dev + (size_t)i * h->G); p.finish(Q_dev + (size_t)i * h->G, f_dev + (size_t)i * h->G); });
+                h->with([&](auto& p) { p.gain_partial(f_dev + (size_t)i * h->G); p.finish(Q_dev + (size_t)i * h->G, f_dev + (size_t)i * h->G, with_loss != 0); });
         } else {
-            h->with([&](auto& p) { const bool fu = p.fuse_reduce(); p.gain_partial(f_dev, n_batch, !fu); p.finish(Q_dev, f_dev, true, n_batch, fu); });
+            h->with([&](auto& p) { const bool fu = p.fuse_reduce(); p.gain_partial(f_dev, n_batch, !fu); p.finish(Q_dev, f_dev, with_loss != 0, n_batch, fu); });
         }
         return check_hip(h, "bfsm_collide_batch");
     )
+}
+
+int bfsm_collide_batch_async(bfsm_handle h, double* Q_dev, const double* f_dev, int n_batch, void* stream) {
+    if (!h) return BFSM_ERR_INVALID;
+    if (!h->full_shard) return fail(h, BFSM_ERR_INVALID, "batched evaluation needs a handle that owns all directions; use bfsm_collide_batch_partial_async + a sum over the ranks");
+    return bfsm_collide_batch_partial_async(h, Q_dev, f_dev, n_batch, 1, stream);
 }
 
 int bfsm_collide_batch(bfsm_handle h, double* Q_dev, const double* f_dev, int n_batch) {

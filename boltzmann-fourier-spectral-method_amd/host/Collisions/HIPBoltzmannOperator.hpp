@@ -49,6 +49,8 @@ public:
 
     // Batch of n_batch <= setMaxBatch() distributions, [n_batch][Nvx*Nvy*Nvz] device arrays, one set of launches.
     void computeCollisionBatch(double* Q, const double* f_in, int n_batch);
+    // Batch x direction shard: partial results of every member [with the loss term]; the caller sums Q over the ranks.
+    void collideBatchPartial(double* Q, const double* f_in, int n_batch, bool with_loss, void* stream = nullptr);
 
     // Sharded evaluation (multi-GPU): partial gain -> caller's RCCL reduce on qhatBuffer() -> finish.
     void gainPartial(const double* f_in, void* stream = nullptr);

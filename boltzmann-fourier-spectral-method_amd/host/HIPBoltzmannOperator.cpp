@@ -47,6 +47,10 @@ void BoltzmannOperator<HIP_Backend>::computeCollisionBatch(double* Q, const doub
     check(bfsm_collide_batch(handle_, Q, f_in, n_batch), "computeCollisionBatch");
 }
 
+void BoltzmannOperator<HIP_Backend>::collideBatchPartial(double* Q, const double* f_in, int n_batch, bool with_loss, void* stream) {
+    check(bfsm_collide_batch_partial_async(handle_, Q, f_in, n_batch, with_loss ? 1 : 0, stream), "collideBatchPartial");
+}
+
 void BoltzmannOperator<HIP_Backend>::gainPartial(const double* f_in, void* stream) {
     check(bfsm_gain_partial(handle_, f_in, stream), "gainPartial");
 }

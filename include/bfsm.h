@@ -138,6 +138,12 @@ int bfsm_collide_async(bfsm_handle h, double* Q_dev, const double* f_dev, void* 
  * bfsm_collide on member i alone.  Batches are independent: on several GPUs they shard without any collective. */
 int bfsm_collide_batch(bfsm_handle h, double* Q_dev, const double* f_dev, int n_batch);
 int bfsm_collide_batch_async(bfsm_handle h, double* Q_dev, const double* f_dev, int n_batch, void* stream);
+/* Batch x direction shard in one call (the two data-parallel axes composed): the handle may own any shard of the
+ * directions; member i of Q_dev receives Re IFFT(this shard's partial Q_gain_hat of member i) [- loss term of member i
+ * if with_loss].  The caller sums Q_dev (n_batch * G doubles) over the ranks with ONE collective for the whole batch;
+ * exactly one rank passes with_loss != 0.  bfsm_collide_batch_async == this with all directions and with_loss = 1. */
+int bfsm_collide_batch_partial_async(bfsm_handle h, double* Q_dev, const double* f_dev, int n_batch, int with_loss,
+                                     void* stream);
 
 /*
  * Sharded evaluation (new functionality: the reference is single-device).  Every rank calls

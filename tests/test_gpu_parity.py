@@ -906,3 +906,27 @@ def test_n16_whole_direction_kernels_and_tile_pipeline_agree_with_oracle(torch_c
         parts.append(Q.cpu().numpy())
         op.destroy()
     assert np.abs(parts[0] + parts[1] - ref).max() <= tol * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("nv,n_gl,n_sph,nb", [(32, 4, 12, 3), (16, 8, 32, 4), (64, 2, 12, 2)])
+def test_batch_times_direction_shards(torch_cuda, oracle, nv, n_gl, n_sph, nb):
+    """SURVEY 8(f4) x 8(e) composed: every rank evaluates its direction shard for the whole batch in one call
+    (bfsm_collide_batch_partial_async), ONE sum over the ranks gives every member's Q."""
+    import bfsm
+    torch = torch_cuda
+    f0 = bfsm.bkw_solution(nv)[0]
+    fs_h = np.stack([bfsm.perturbed_input(f0, seed=7 + i, amp=0.03 * (i + 1)) for i in range(nb)])
+    fs = torch.from_numpy(fs_h).cuda()
+    B, P = n_gl * n_sph, 3
+    total = torch.zeros_like(fs)
+    for r in range(P):
+        op = _make(bfsm, nv, n_gl, n_sph, shard=bfsm.shard_range(B, r, P), max_batch=nb)
+        Q = torch.empty_like(fs)
+        op.collideBatchPartial(Q, fs, nb, r == 0)
+        torch.cuda.synchronize()
+        total += Q                                   # what the all-reduce of the batch does
+        op.destroy()
+    got = total.cpu().numpy()
+    for i in range(nb):
+        ref = _oracle(oracle, fs_h[i], n_gl, n_sph)
+        assert np.abs(got[i] - ref).max() <= TOL64 * np.abs(ref).max()

@@ -162,3 +162,28 @@ def test_oracle_reproduces_committed_q_fixtures(oracle):
         want = np.load(os.path.join(HERE, "golden", name))
         got = oracle.collide(inp, gl, sph, GAMMA, B_GAMMA, L)
         assert np.abs(got - want).max() <= 1e-14 * np.abs(want).max()      # thread count / libm independent
+
+
+def test_cpu_driver_prints_the_archived_lines(oracle):
+    """oracle/maxwell_bkw_oracle: the reference's CPU driver maxwell_bkw_fftw.cpp (BASELINE config 1, "reference
+    plumbing") restated over the oracle -- same flags, same report.  Run as `maxwell_bkw_fftw_ex --Nv 32 --Ns 12` its
+    error lines are, character for character, those archived in Results/maxwell_bkw_fftw_atomics.txt:19-21; config 1
+    itself (--Nv 16 --Ngl 8 --Ns 32) prints the values SURVEY.md 8(c) recorded."""
+    import re
+    import subprocess
+    root = os.path.dirname(HERE)
+    subprocess.check_call(["make", "-C", os.path.join(root, "oracle"), "-s"])
+    exe = os.path.join(root, "oracle", "maxwell_bkw_oracle")
+    ddir = os.path.join(root, "boltzmann-fourier-spectral-method_amd", "data", "sph_design")
+    out = subprocess.run([exe, "--Nv", "32", "--Ns", "12", "-t", "2", "--design-dir", ddir], capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr
+    assert "Run arguments:\nNv = 32\nNs = 12\ntrials = 2" in out.stdout and "Total number of samples taken: 2" in out.stdout
+    row = GOLD["published"][0]
+    for k in ("L1", "L2", "Linf"):
+        assert re.search(k + r" error: (\S+)", out.stdout).group(1) == "%.8e" % row[k]
+    out = subprocess.run([exe, "--Nv", "16", "--Ngl", "8", "--Ns", "32", "--design-dir", ddir], capture_output=True, text=True,
+                         timeout=600)
+    row = [r for r in GOLD["survey"] if r["nv"] == 16 and r["n_gl"] == 8][0]
+    for k in ("L1", "L2", "Linf"):
+        assert float(re.search(k + r" error: (\S+)", out.stdout).group(1)) == pytest.approx(row[k], rel=6e-9)
