@@ -553,12 +553,10 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
             auto one_sign = [&](auto conj_tag) {
                 constexpr bool CONJ = decltype(conj_tag)::value;
                 // the second sign re-forms its phase factors from an opaque copy of c0: sharing them between the signs
-                // would keep a whole extra tile of values alive across the first transform (registers: spills)
-#ifndef BFSM_KA_SHARE_PH
+                // would keep a whole extra tile of values alive across the first transform (registers: spills;
+                // measured with the factors shared: KA 1.09 -> 2.05 ms at config 3).  Fetching the phz factors one
+                // direction ahead was measured too: no difference.
                 const cx<T> c0s = CONJ ? ctx.opaque_cx(c0) : c0;
-#else
-                const cx<T> c0s = c0;
-#endif
                 cx<T> v[E];
 #pragma unroll
                 for (int m = 0; m < E; ++m) {

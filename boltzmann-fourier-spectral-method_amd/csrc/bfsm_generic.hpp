@@ -9,8 +9,8 @@
 //     hadamard_product (Kernels.cu:62-74)                                        -> load side of the first forward pass
 //     beta2 * f_hat (Kernels.cu:126-159)                                         -> load side of the first tail pass
 //     copy_to_complex (Kernels.cu:4-16)                                          -> load side of the first pass of FFT(f)
-// and a deterministic, atomic-free accumulate (atomic_tensor_contraction, Kernels.cu:79-123).  12 array passes per
-// direction: about half the speed of the fused pipeline, all sizes.  Layouts are the reference's own: physical
+// and a deterministic, atomic-free accumulate (atomic_tensor_contraction, Kernels.cu:79-123).  18 array moves per
+// direction instead of 6: a correct fallback for every size (measured 1.0-1.3 TB/s algorithmic), not a tuned path.  Layouts are the reference's own: physical
 // [x][y][z], spectral [lx][ly][lz], z contiguous.
 //
 // Like bfsm_core.hpp the kernel bodies are templates over an execution context, so tests/emu runs the same code on the
@@ -121,32 +121,42 @@ BFSM_HD void gen_dft(cx<T>* x, int sgn) {
     }
 }
 
-// One Stockham pass of radix R over C lines of n points held in LDS as [point][line] (row stride LS).
-template <int R, typename T, class Ctx>
-BFSM_HD void gen_pass(const cx<T>* src, cx<T>* dst, const cx<T>* tw, int n, int ns, int C, int LS, int sgn, Ctx& ctx) {
-    const int m = n / R, tasks = m * C;
-    for (int t = ctx.tid(); t < tasks; t += ctx.nthreads()) {
-        const int col = t % C, j = t / C;
-        const int k = j % ns;                          // position inside the sub-transform done so far
-        const int tstep = n / (ns * R);                // twiddle exp(sgn 2 pi i k q / (ns R)) = tw[k q tstep]
+// Lines per workgroup and thread geometry of a pass: 256 threads = 16 lines x 16 "rows"; thread (row, line) walks the
+// points row, row + 16, ... of its line, so no per-element integer division is ever needed.
+constexpr int GEN_C = 16;
+constexpr int GEN_LS = GEN_C + 1;
+
+// One Stockham pass of radix R over GEN_C lines of n points held in LDS as [point][line] (row stride GEN_LS).
+// ns = product of the radices already applied; NS_POW2: ns is a power of two (shift / mask instead of division: the
+// plan orders the radices 4, 2 first and 3, 5 last, so only passes behind an odd radix take the general form).
+template <int R, bool NS_POW2, typename T, class Ctx>
+BFSM_HD void gen_pass(const cx<T>* src, cx<T>* dst, const cx<T>* tw, int n, int ns, int sgn, Ctx& ctx) {
+    const int m = n / R;
+    const int col = ctx.tid() % GEN_C, row = ctx.tid() / GEN_C;
+    const int tstep = n / (ns * R);                    // twiddle exp(sgn 2 pi i k q / (ns R)) = tw[k q tstep], k q tstep < n
+    const int sh = NS_POW2 ? (31 - __builtin_clz((unsigned)ns)) : 0;
+    for (int j = row; j < m; j += GEN_THREADS / GEN_C) {
+        const int hi = NS_POW2 ? (j >> sh) : (j / ns);
+        const int k = NS_POW2 ? (j & (ns - 1)) : (j - hi * ns);   // position inside the sub-transform done so far
         cx<T> x[R];
 #pragma unroll
         for (int q = 0; q < R; ++q) {
-            x[q] = src[(j + q * m) * LS + col];
+            x[q] = src[(j + q * m) * GEN_LS + col];
             if (q > 0) {
-                const cx<T> w = tw[(k * q * tstep) % n];
+                const cx<T> w = tw[k * q * tstep];
                 x[q] = sgn < 0 ? cmul(x[q], w) : cmulc(x[q], w);
             }
         }
         gen_dft<R, T>(x, sgn);
-        const int j0 = (j / ns) * ns * R + k;
+        const int j0 = hi * ns * R + k;
 #pragma unroll
-        for (int q = 0; q < R; ++q) dst[(j0 + q * ns) * LS + col] = x[q];
+        for (int q = 0; q < R; ++q) dst[(j0 + q * ns) * GEN_LS + col] = x[q];
     }
 }
 
-// Batched 1-D transform along one axis.  grid = (column blocks, batch).  Workgroup: GEN_THREADS threads, LDS = two
-// buffers of n x (C + 1) complex.
+// Batched 1-D transform along one axis.  grid = (blocks of GEN_C lines, batch).  Workgroup: GEN_THREADS threads, LDS =
+// two buffers of n x (GEN_C + 1) complex.  A "line" is the set of n points along the transformed axis; consecutive
+// lines are consecutive in z (axes x, y) or consecutive (x, y) pairs (axis z).
 template <typename T, class Ctx>
 BFSM_HD void body_gen_fft(const GenFftParams<T>& prm, Ctx& ctx) {
     const int nx = prm.nx, ny = prm.ny, nz = prm.nz;
@@ -154,33 +164,35 @@ BFSM_HD void body_gen_fft(const GenFftParams<T>& prm, Ctx& ctx) {
     const int n = axis == 0 ? nx : (axis == 1 ? ny : nz);
     const size_t G = (size_t)nx * ny * nz;
     const int ncols = (int)(G / (size_t)n);
-    const int C = prm.C, LS = C + 1;
-    const int col0 = ctx.bx() * C;
     const int b = ctx.by();
     cx<T>* buf0 = ctx.template lds<cx<T>>();
-    cx<T>* buf1 = buf0 + (size_t)n * LS;
-    const int total = n * C;
-    // element (pt, col) of this workgroup's block -> linear index inside one array
-    auto index_of = [&](int pt, int col) -> size_t {
-        if (axis == 0) return (size_t)pt * ny * nz + col;                         // col = y * nz + z
-        if (axis == 1) return ((size_t)(col / nz) * ny + pt) * nz + (col % nz);   // col = x * nz + z
-        return (size_t)col * nz + pt;                                             // col = x * ny + y
-    };
-    for (int e = ctx.tid(); e < total; e += ctx.nthreads()) {
-        // lanes run along the contiguous (z) direction of memory
-        const int pt = axis == 2 ? e % n : e / C, cl = axis == 2 ? e / n : e % C;
-        const int col = col0 + cl;
+    cx<T>* buf1 = buf0 + (size_t)n * GEN_LS;
+    // Global <-> LDS: lanes run along the contiguous (z) direction of memory.  Axes x, y: 16 consecutive lanes take
+    // the 16 lines of the block at one point; axis z: 16 consecutive lanes take 16 consecutive points of one line.
+    const int lane16 = ctx.tid() % GEN_C, grp = ctx.tid() / GEN_C;
+    const int cl = axis == 2 ? grp : lane16;           // line of the block this thread moves
+    const int p0 = axis == 2 ? lane16 : grp;           // first point; then steps of 16
+    const int col = ctx.bx() * GEN_C + cl;
+    const bool live = col < ncols;
+    // offset of point 0 of the line and the stride between its points; (ix, iy, iz) of point 0 for the fused factors
+    size_t base = 0, ps = 1;
+    int i0x = 0, i0y = 0, i0z = 0;
+    if (axis == 0) { base = (size_t)col; ps = (size_t)ny * nz; i0y = col / nz; i0z = col - i0y * nz; }
+    else if (axis == 1) { i0x = col / nz; i0z = col - i0x * nz; base = (size_t)i0x * ny * nz + i0z; ps = (size_t)nz; }
+    else { i0x = col / ny; i0y = col - i0x * ny; base = (size_t)col * nz; ps = 1; }
+    const size_t in_off = (size_t)b * prm.in_bstride;
+    for (int pt = p0; pt < n; pt += GEN_THREADS / GEN_C) {
         cx<T> v = {(T)0, (T)0};
-        if (col < ncols) {
-            const size_t idx = index_of(pt, col);
+        if (live) {
+            const size_t idx = base + (size_t)pt * ps;
             if (prm.mode == GEN_REAL) {
-                v.x = (T) static_cast<const double*>(prm.in)[(size_t)b * prm.in_bstride + idx];
+                v.x = (T) static_cast<const double*>(prm.in)[in_off + idx];
             } else {
-                v = static_cast<const cx<T>*>(prm.in)[(size_t)b * prm.in_bstride + idx];
+                v = static_cast<const cx<T>*>(prm.in)[in_off + idx];
                 if (prm.mode == GEN_PRODUCT) {
-                    v = cmul(v, prm.in2[(size_t)b * prm.in_bstride + idx]);
+                    v = cmul(v, prm.in2[in_off + idx]);
                 } else if (prm.mode == GEN_PHASE || prm.mode == GEN_BETA2) {
-                    const int iz = (int)(idx % nz), iy = (int)((idx / nz) % ny), ix = (int)(idx / ((size_t)nz * ny));
+                    const int ix = axis == 0 ? pt : i0x, iy = axis == 1 ? pt : i0y, iz = axis == 2 ? pt : i0z;
                     if (prm.mode == GEN_PHASE) {
                         const size_t d = (size_t)(prm.dir0 + (b >> 1));
                         const cx<T> ph = cmul(cmul(prm.phx[d * nx + ix], prm.phy[d * ny + iy]), prm.phz[d * nz + iz]);
@@ -193,7 +205,7 @@ BFSM_HD void body_gen_fft(const GenFftParams<T>& prm, Ctx& ctx) {
                 }
             }
         }
-        buf0[pt * LS + cl] = v;
+        buf0[pt * GEN_LS + cl] = v;
     }
     ctx.sync();
     cx<T>* src = buf0;
@@ -201,18 +213,20 @@ BFSM_HD void body_gen_fft(const GenFftParams<T>& prm, Ctx& ctx) {
     int ns = 1;
     for (int r = 0; r < prm.n_radix; ++r) {
         const int R = prm.radix[r];
-        if (R == 2) gen_pass<2, T>(src, dst, prm.tw, n, ns, C, LS, prm.sign, ctx);
-        else if (R == 3) gen_pass<3, T>(src, dst, prm.tw, n, ns, C, LS, prm.sign, ctx);
-        else if (R == 4) gen_pass<4, T>(src, dst, prm.tw, n, ns, C, LS, prm.sign, ctx);
-        else gen_pass<5, T>(src, dst, prm.tw, n, ns, C, LS, prm.sign, ctx);
+        const bool p2 = (ns & (ns - 1)) == 0;
+        if (R == 4) gen_pass<4, true, T>(src, dst, prm.tw, n, ns, prm.sign, ctx);          // radices 4, 2 come first
+        else if (R == 2) gen_pass<2, true, T>(src, dst, prm.tw, n, ns, prm.sign, ctx);
+        else if (R == 3 && p2) gen_pass<3, true, T>(src, dst, prm.tw, n, ns, prm.sign, ctx);
+        else if (R == 3) gen_pass<3, false, T>(src, dst, prm.tw, n, ns, prm.sign, ctx);
+        else if (p2) gen_pass<5, true, T>(src, dst, prm.tw, n, ns, prm.sign, ctx);
+        else gen_pass<5, false, T>(src, dst, prm.tw, n, ns, prm.sign, ctx);
         ns *= R;
         ctx.sync();
         cx<T>* t = src; src = dst; dst = t;
     }
-    for (int e = ctx.tid(); e < total; e += ctx.nthreads()) {
-        const int pt = axis == 2 ? e % n : e / C, cl = axis == 2 ? e / n : e % C;
-        const int col = col0 + cl;
-        if (col < ncols) prm.out[(size_t)b * prm.out_bstride + index_of(pt, col)] = src[pt * LS + cl];
+    if (live) {
+        const size_t out_off = (size_t)b * prm.out_bstride;
+        for (int pt = p0; pt < n; pt += GEN_THREADS / GEN_C) prm.out[out_off + base + (size_t)pt * ps] = src[pt * GEN_LS + cl];
     }
 }
 
@@ -416,9 +430,7 @@ struct GenericPipeline {
         p.nx = nx; p.ny = ny; p.nz = nz; p.axis = axis; p.sign = sign;
         const int n = axis_len(axis);
         const int ncols = (int)(G / (size_t)n);
-        int C = n <= 128 ? 16 : 8;
-        if (axis == 1 && nz % C != 0) C = nz % 8 == 0 ? 8 : (nz % 4 == 0 ? 4 : 2);   // a block never straddles an x plane
-        if (C > ncols) C = ncols;
+        const int C = GEN_C;
         p.C = C;
         p.n_radix = (int)radix[axis].size();
         for (int i = 0; i < p.n_radix; ++i) p.radix[i] = radix[axis][i];
@@ -432,26 +444,28 @@ struct GenericPipeline {
     void gain_partial(const double* f_dev, int nb = 1, bool = true) {
         (void)nb;
         const double Gc = (double)G * sizeof(cx<T>);
-        be->mark(BFSM_K_FFT_F, 5.5 * Gc);
+        be->mark(BFSM_K_FFT_F, 1.5 * Gc);
         pass(f_dev, nullptr, fhat, 1, 2, -1, GEN_REAL, 0, 0);
-        be->mark(-1, 0); pass(fhat, nullptr, fhat, 1, 1, -1, GEN_PLAIN, 0, 0);
-        be->mark(-1, 0); pass(fhat, nullptr, fhat, 1, 0, -1, GEN_PLAIN, 0, 0);
+        be->mark(BFSM_K_FFT_F, 2.0 * Gc); pass(fhat, nullptr, fhat, 1, 1, -1, GEN_PLAIN, 0, 0);
+        be->mark(BFSM_K_FFT_F, 2.0 * Gc); pass(fhat, nullptr, fhat, 1, 0, -1, GEN_PLAIN, 0, 0);
         bool first = true;
         for (const Chunk& c : plan.chunks) {
             const int nb2 = 2 * c.n;
             // A1, A2 = IFFT(alpha f_hat / G), IFFT(conj(alpha) f_hat / G): members 2d, 2d + 1 of `a`
-            be->mark(BFSM_K_GAIN_INV, 11.0 * c.n * Gc);
+            // accounting: the SURVEY 8(d) model attributes 2 array passes per direction to this group (the inverse
+            // transforms), 3 to the next (product + forward transform) and 1 to the accumulate; the path moves more
+            be->mark(BFSM_K_GAIN_INV, 2.0 * c.n * Gc);
             pass(fhat, nullptr, a, nb2, 0, +1, GEN_PHASE, 0, G, c.dir0);
-            be->mark(-1, 0); pass(a, nullptr, a, nb2, 1, +1, GEN_PLAIN, G, G);
-            be->mark(-1, 0); pass(a, nullptr, a, nb2, 2, +1, GEN_PLAIN, G, G);
+            be->mark(BFSM_K_GAIN_INV, 0); pass(a, nullptr, a, nb2, 1, +1, GEN_PLAIN, G, G);
+            be->mark(BFSM_K_GAIN_INV, 0); pass(a, nullptr, a, nb2, 2, +1, GEN_PLAIN, G, G);
             // P_hat = FFT(A1 * A2): the product is formed on the load side of the first forward pass and written over
             // A1 (members 2d, stride 2G), then transformed in place
-            be->mark(BFSM_K_GAIN_LINE, 8.0 * c.n * Gc);
+            be->mark(BFSM_K_GAIN_LINE, 3.0 * c.n * Gc);
             pass(a, a + G, a, c.n, 2, -1, GEN_PRODUCT, 2 * G, 2 * G);
-            be->mark(-1, 0); pass(a, nullptr, a, c.n, 1, -1, GEN_PLAIN, 2 * G, 2 * G);
-            be->mark(-1, 0); pass(a, nullptr, a, c.n, 0, -1, GEN_PLAIN, 2 * G, 2 * G);
+            be->mark(BFSM_K_GAIN_LINE, 0); pass(a, nullptr, a, c.n, 1, -1, GEN_PLAIN, 2 * G, 2 * G);
+            be->mark(BFSM_K_GAIN_LINE, 0); pass(a, nullptr, a, c.n, 0, -1, GEN_PLAIN, 2 * G, 2 * G);
             GenAccParams<T> ka{a, 2 * G, qhat, dirw, rdir, beta1, c.dir0, c.n, n2stride, first ? 1 : 0, nx, ny, nz};
-            be->mark(BFSM_K_GAIN_FWD, (1.0 * c.n + 2.0) * Gc);
+            be->mark(BFSM_K_GAIN_FWD, 1.0 * c.n * Gc);
             be->template launch_gen<GK::Acc, T>((int)((G + GEN_THREADS - 1) / GEN_THREADS), 1, GEN_THREADS, 0, ka);
             first = false;
         }
@@ -468,17 +482,17 @@ struct GenericPipeline {
         const double Gc = (double)G * sizeof(cx<T>);
         cx<T>* tg = tail;
         cx<T>* tl = tail + G;
-        be->mark(BFSM_K_TAIL, (with_loss ? 12.0 : 6.0) * Gc);
+        be->mark(BFSM_K_TAIL, (with_loss ? 7.0 : 3.5) * Gc);
         pass(qhat, nullptr, tg, 1, 0, +1, GEN_PLAIN, 0, 0);
-        be->mark(-1, 0); pass(tg, nullptr, tg, 1, 1, +1, GEN_PLAIN, 0, 0);
-        be->mark(-1, 0); pass(tg, nullptr, tg, 1, 2, +1, GEN_PLAIN, 0, 0);
+        be->mark(BFSM_K_TAIL, 0); pass(tg, nullptr, tg, 1, 1, +1, GEN_PLAIN, 0, 0);
+        be->mark(BFSM_K_TAIL, 0); pass(tg, nullptr, tg, 1, 2, +1, GEN_PLAIN, 0, 0);
         if (with_loss) {
-            be->mark(-1, 0); pass(fhat, nullptr, tl, 1, 0, +1, GEN_BETA2, 0, 0);
-            be->mark(-1, 0); pass(tl, nullptr, tl, 1, 1, +1, GEN_PLAIN, 0, 0);
-            be->mark(-1, 0); pass(tl, nullptr, tl, 1, 2, +1, GEN_PLAIN, 0, 0);
+            be->mark(BFSM_K_TAIL, 0); pass(fhat, nullptr, tl, 1, 0, +1, GEN_BETA2, 0, 0);
+            be->mark(BFSM_K_TAIL, 0); pass(tl, nullptr, tl, 1, 1, +1, GEN_PLAIN, 0, 0);
+            be->mark(BFSM_K_TAIL, 0); pass(tl, nullptr, tl, 1, 2, +1, GEN_PLAIN, 0, 0);
         }
         GenCombineParams<T> kc{tg, tl, f_dev, Q_dev, G, with_loss ? 1 : 0};
-        be->mark(-1, 0);
+        be->mark(BFSM_K_TAIL, 0);
         be->template launch_gen<GK::Combine, T>((int)((G + GEN_THREADS - 1) / GEN_THREADS), 1, GEN_THREADS, 0, kc);
     }
 

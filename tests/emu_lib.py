@@ -14,7 +14,8 @@ def lib():
     if _LIB is None:
         subprocess.check_call(["make", "-C", os.path.join(_HERE, "emu"), "-s"])
         from bfsm import capi
-        L = ctypes.CDLL(os.path.join(_HERE, "emu", "libbfsm_emu.so"))
+        # BFSM_EMU_LIB: an alternative build of the same emulator (the AddressSanitizer build of tests/emu/Makefile)
+        L = ctypes.CDLL(os.environ.get("BFSM_EMU_LIB") or os.path.join(_HERE, "emu", "libbfsm_emu.so"))
         dp = ctypes.POINTER(ctypes.c_double)
         L.bfsm_emu_collide.argtypes = [ctypes.POINTER(capi.Desc), dp, dp, dp]
         L.bfsm_emu_collide.restype = ctypes.c_int
