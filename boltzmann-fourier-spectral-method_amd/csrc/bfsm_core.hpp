@@ -129,7 +129,9 @@ struct Wg {
     // lets two workgroups share a CU; the 2-D tile kernels keep N columns.
     static constexpr int NPL = N > 64 ? 64 : N;
     static constexpr int LINE_THREADS = NPL * T;
-    static constexpr int LINE_LDS_ELEMS = N * (NPL + 1);
+    // N rows for the exchanges; N + 2 so that the Hermitian line kernel can stage the stored halves (N/2 + 1 rows) of
+    // both arrays side by side
+    static constexpr int LINE_LDS_ELEMS = (N + 2) * (NPL + 1);
     static_assert(E * T == N && Q * T == E && N % NPL == 0, "geometry");
 };
 
@@ -746,21 +748,44 @@ BFSM_HD void body_nyq_rows(const NyqRowsParams<T>& prm, Ctx& ctx) {
     }
 }
 
-// x-line of A' in the Hermitian mode: rows idx = u + T*m of column col = y*N + z.  Two branch-free steps so that all
-// loads of both arrays issue back to back: (1) raw loads -- m < E/2 are stored planes, m > E/2 mirrored planes,
-// m == E/2 (idx = N/2 + u) the stored Nyquist plane for u == 0 and a mirrored plane otherwise; (2) conjugation of
-// the mirrored rows plus the exact Nyquist terms (-1)^y R1[idx](z) + (-1)^z R2[idx](y).
+// x-lines of A1', A2' in the Hermitian mode: rows idx = u + T*m of column col = y*N + z.  Only the planes 0 .. N/2 are
+// stored; a row idx > N/2 is the conjugate of the stored row N - idx of the SAME column (plus the exact Nyquist terms
+// added by hermitian_line_fix), and that stored row belongs to another thread's (another wave's) share of the line.
+// Every stored row is therefore fetched from HBM exactly once, by the thread that owns it (m < E/2, and m == E/2 for
+// u == 0: the Nyquist plane), streamed; the threads that need it as a mirror row get it through LDS.  (Round 1 let both
+// threads read it from global memory: 1.5x over-fetch measured, the second read missing L1 and often L2.)
 // colrow = first column of this workgroup's block (uniform), pl = lane offset in bytes.
 template <int N, typename T, class Ctx>
-BFSM_HD void hermitian_line_load(cx<T>* v, const cx<T>* A, int colrow, unsigned pl, int u, Ctx& ctx) {
-    constexpr int E = Wg<N>::E, TT = Wg<N>::T, MS = E / 2;
+BFSM_HD void hermitian_lines_load(cx<T>* a, cx<T>* b, const cx<T>* A1, const cx<T>* A2, int colrow, unsigned pl, int p,
+                                  int u, cx<T>* lds, Ctx& ctx) {
+    constexpr int E = Wg<N>::E, TT = Wg<N>::T, MS = E / 2, LS = Wg<N>::NPL + 1, H = N / 2;
+    constexpr bool UNI = Wg<N>::NPL % 64 == 0;
     static_assert(TT * MS == N / 2, "split row");
+    cx<T>* ha = lds;
+    cx<T>* hb = lds + (H + 1) * LS;
 #pragma unroll
-    for (int m = 0; m < E; ++m) {
-        const int idx = u + TT * m;
-        const int plane = (m < MS) ? idx : ((m > MS || u != 0) ? N - idx : idx);
-        // each stored row is read twice per iteration: keep it cacheable
-        v[m] = ctx.template ld_at<Wg<N>::NPL % 64 == 0>(A + (size_t)plane * N * N + colrow, pl);
+    for (int m = 0; m < MS; ++m) {
+        a[m] = ctx.template ld_stream_at<UNI>(A1 + (size_t)(u + TT * m) * N * N + colrow, pl);
+        b[m] = ctx.template ld_stream_at<UNI>(A2 + (size_t)(u + TT * m) * N * N + colrow, pl);
+    }
+    if (u == 0) {                                  // the stored Nyquist plane lx = N/2 is its own mirror
+        a[MS] = ctx.template ld_stream_at<UNI>(A1 + (size_t)H * N * N + colrow, pl);
+        b[MS] = ctx.template ld_stream_at<UNI>(A2 + (size_t)H * N * N + colrow, pl);
+    }
+    ctx.sync();                                    // the previous users of the buffer (last exchange) are done
+#pragma unroll
+    for (int m = 0; m < MS; ++m) {
+        ctx.lds_st(ha + (u + TT * m) * LS + p, a[m]);
+        ctx.lds_st(hb + (u + TT * m) * LS + p, b[m]);
+    }
+    ctx.sync();
+#pragma unroll
+    for (int m = MS; m < E; ++m) {
+        if (m > MS || u != 0) {
+            const int q = N - (u + TT * m);        // stored row whose conjugate this row is, 1 <= q < N/2
+            a[m] = ctx.lds_ld(ha + q * LS + p);
+            b[m] = ctx.lds_ld(hb + q * LS + p);
+        }
     }
 }
 
@@ -800,9 +825,8 @@ BFSM_HD void body_gain_line_acc_h(const GainLineAccHParams<T>& prm, Ctx& ctx) {
         const size_t abase = (size_t)ctx.bz() * prm.a_bstride + (size_t)d * NH * N * N;
         const cx<T>* R = prm.r + (size_t)ctx.bz() * prm.r_bstride + (size_t)d * 4 * NQ * N;
         cx<T> a[E], b[E];
-        hermitian_line_load<N, T>(a, prm.a1 + abase, colrow, pl, u, ctx);
+        hermitian_lines_load<N, T>(a, b, prm.a1 + abase, prm.a2 + abase, colrow, pl, p, u, lds, ctx);
         hermitian_line_fix<N, T>(a, R, y, z0, p, u, ctx);
-        hermitian_line_load<N, T>(b, prm.a2 + abase, colrow, pl, u, ctx);     // in flight while a is transformed
         fft_line_np<N, NPL, +1, T>(a, lds, p, u, twr, ctx);
         hermitian_line_fix<N, T>(b, R + (size_t)2 * NQ * N, y, z0, p, u, ctx);
         fft_line_np<N, NPL, +1, T>(b, lds, p, u, twr, ctx);

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BFSM_VERSION 1
+#define BFSM_VERSION 2   /* 2: any-box grids, bfsm_collide_batch_partial_async, BFSM_FLAG_NO_SMALL_PATH */
 
 enum {
     BFSM_OK = 0,

@@ -37,7 +37,7 @@ def test_no_compute_entry_points_without_gpu_but_metadata_works(libpath):
     from bfsm import capi
     L = capi.load_library()
     assert L.bfsm_backend_name() == b"HIP"
-    assert L.bfsm_version() == 1
+    assert L.bfsm_version() == 2
 
 
 def test_descriptor_validation_errors_are_reported(libpath):
