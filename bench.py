@@ -323,14 +323,17 @@ def main():
         # dominant kernel, timed live with HIP events on the stream it is launched on (BFSM_FLAG_PROFILE)
         opp = make(True)
         s = torch.cuda.current_stream().cuda_stream
+        def profiled_eval():          # the same entry point the timed loop uses, so the same kernels are timed
+            if world == 1:
+                opp.computeCollisionAsync(Q, f, s)
+            else:
+                opp.collidePartial(Q, f, rank == 0, s)
         for _ in range(2):
-            opp.gainPartial(f, s)
-            opp.finish(Q, f, s)
+            profiled_eval()
         torch.cuda.synchronize()
         reps, acc = 5, None
         for _ in range(reps):
-            opp.gainPartial(f, s)
-            opp.finish(Q, f, s)
+            profiled_eval()
             torch.cuda.synchronize()
             cn = opp.counters()
             cur = [(cn.kernel_ms[i], cn.kernel_alg_bytes[i], cn.kernel_launches[i]) for i in range(len(bfsm.KERNEL_NAMES))]
