@@ -930,3 +930,30 @@ def test_batch_times_direction_shards(torch_cuda, oracle, nv, n_gl, n_sph, nb):
     for i in range(nb):
         ref = _oracle(oracle, fs_h[i], n_gl, n_sph)
         assert np.abs(got[i] - ref).max() <= TOL64 * np.abs(ref).max()
+
+
+def test_synchronize_waits_for_every_stream_the_handle_used(torch_cuda, oracle):
+    """include/bfsm.h: bfsm_synchronize waits for every stream that was passed to the handle since the last
+    synchronize, not only the most recent one.  Two evaluations are enqueued on two different streams (ordered by an
+    event, as the header requires for calls that share the scratch); after ONE bfsm_synchronize both results are
+    complete without any torch-side synchronisation."""
+    import bfsm
+    torch = torch_cuda
+    nv, n_gl, n_sph = 64, 4, 48
+    f_h = bfsm.perturbed_input(bfsm.bkw_solution(nv)[0])
+    ref = _oracle(oracle, f_h, n_gl, n_sph)
+    op = _make(bfsm, nv, n_gl, n_sph)
+    f = torch.from_numpy(f_h).cuda()
+    Qa, Qb = torch.zeros_like(f), torch.zeros_like(f)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    op.computeCollisionAsync(Qa, f, s1.cuda_stream)
+    ev = torch.cuda.Event()
+    ev.record(s1)
+    s2.wait_event(ev)                      # same handle, same scratch: the second call is ordered behind the first
+    op.computeCollisionAsync(Qb, 2.0 * f, s2.cuda_stream)
+    op.synchronize()                       # must cover s1 AND s2
+    a, b = Qa.cpu().numpy(), Qb.cpu().numpy()
+    assert np.abs(a - ref).max() <= TOL64 * np.abs(ref).max()
+    assert np.abs(b - 4.0 * ref).max() <= TOL64 * np.abs(4.0 * ref).max()
+    op.destroy()
