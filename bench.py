@@ -403,7 +403,11 @@ def main():
                                    f"B={B} directions, BKW f (t=6.5), Maxwell molecules",
                        "directions_per_gpu": B // world, "parallelism": f"direction-shard x{world} + 1 all-reduce",
                        "timing": "in-order: evaluation i+1 starts after evaluation i and its collective have finished",
-                       "collective_overlap": False, "collective": collective},
+                       "collective_overlap": False, "collective": collective,
+                       # every direction: its own two inverse transforms and the x part of its forward transform; the
+                       # (y,z) part of the forward transform is applied to the weighted sum of a segment's directions
+                       # (linearity: same result, same bytes streamed)
+                       "kc_sum_before_transform": True},
             "achieved_alg_GBps": alg_gbps, "frac_of_hbm_peak": alg_gbps / (HBM_PEAK_GBPS * world),
             "frac_of_measured_copy_ceiling": alg_gbps / (HBM_COPY_CEILING_GBPS * world),
             "alg_bytes_per_eval": alg_bytes,
