@@ -629,6 +629,69 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
     }
 }
 
+// KA at N = 32 on a PAIR of tiles.  A 32 x 32 tile gives 128 threads = rows of 32 lanes, so a wave straddles two values of
+// u and twiddles / phz factors would be per-lane data.  The two signs of a direction are two tiles with the same f_hat
+// plane and conjugate phases: they are processed side by side as one 32 x 64 panel -- lanes 0..31 the alpha tile, lanes
+// 32..63 the conj(alpha) tile -- by 256 threads, so every wave has ONE u: twiddles and phz factors are scalar loads into
+// SGPRs as at N >= 64, and the sign costs one multiply per point instead of a select.  The line transforms treat the 64
+// columns independently; the transposing exchange transposes each half on its own.  Same parameters, grid and results.
+template <int N> constexpr bool pair_tile() {
+#ifdef BFSM_NO_PAIR_TILE
+    return false;
+#else
+    return N == 32;
+#endif
+}
+template <int N> constexpr int pair_threads() { return 2 * N * Wg<N>::T; }
+template <int N, typename T> constexpr size_t pair_lds_bytes() { return (size_t)N * (2 * N + 1) * sizeof(cx<T>); }
+
+template <int N, typename T, class Ctx>
+BFSM_HD void body_gain_inv_pair(const GainInvParams<T>& prm, Ctx& ctx) {
+    constexpr int E = Wg<N>::E, TT = Wg<N>::T, NP = 2 * N, LS = NP + 1;
+    const int tid = ctx.tid(), lane = tid % NP, u = ctx.uniform(tid / NP, NP);
+    const int h = lane / N, p = lane % N;                  // h: 0 = alpha tile (A1'), 1 = conj(alpha) tile (A2')
+    const T sg = h ? (T)-1 : (T)1;
+    const int lxi = ctx.bx();
+    cx<T>* lds = ctx.template lds<cx<T>>();
+    Twiddles<N, T> twr;
+    twr.load(prm.tw, u, ctx);
+    const size_t bz = (size_t)ctx.bz();
+    const cx<T>* src = prm.fhat + bz * N * N * N + (size_t)lxi * N * N;
+    cx<T> fh[E];
+#pragma unroll
+    for (int m = 0; m < E; ++m) fh[m] = src[(u + TT * m) * N + p];  // [lz = u + T m][ly = p], both halves the same plane
+    const int d_begin = ctx.by() * prm.per_group;
+    int d_end = d_begin + prm.per_group;
+    if (d_end > prm.n_dir) d_end = prm.n_dir;
+    cx<T> py = {(T)0, (T)0};
+    if (d_begin < d_end) py = prm.phy[(size_t)(prm.dir0 + d_begin) * N + p];
+    for (int d = d_begin; d < d_end; ++d) {
+        const size_t b = (size_t)(prm.dir0 + d);
+        cx<T> c0 = cmul(ctx.ldc(prm.phx + b * N + lxi), py);
+        c0.y *= sg;                                        // conj(c0 * phz) = conj(c0) * conj(phz): both factors get the sign
+        if (d + 1 < d_end) py = prm.phy[(size_t)(prm.dir0 + d + 1) * N + p];
+        cx<T> v[E];
+#pragma unroll
+        for (int m = 0; m < E; ++m) {
+            cx<T> z = ctx.ldc(prm.phz + b * N + u + TT * m);       // wave-uniform: scalar load
+            z.y *= sg;
+            v[m] = cmul(fh[m], cmul(c0, z));               // alpha f_hat / G  |  conj(alpha) f_hat / G
+        }
+        fft_line_np<N, NP, +1, T, false, SYNC_PRE | SYNC_POST>(v, lds, lane, u, twr, ctx);   // along lz, 64 columns
+#pragma unroll
+        for (int m = 0; m < E; ++m) ctx.lds_st(lds + (u + TT * m) * LS + lane, v[m]);          // row a', column (h, c)
+        ctx.sync();
+#pragma unroll
+        for (int m = 0; m < E; ++m) v[m] = ctx.lds_ld(lds + p * LS + h * N + (u + TT * m));    // own half, transposed
+        ctx.sync();
+        fft_line_np<N, NP, +1, T, false, SYNC_POST>(v, lds, lane, u, twr, ctx);                 // along ly
+        cx<T>* dst = (h ? prm.a2 : prm.a1) + bz * prm.a_bstride + ((size_t)d * prm.planes + lxi) * N * N;
+#pragma unroll
+        for (int m = 0; m < E; ++m)   // [y = u + T m][z = p]
+            ctx.template st_stream_at<false>(dst + (size_t)(u + TT * m) * N, (unsigned)p * (unsigned)sizeof(cx<T>), v[m]);
+    }
+}
+
 // KB.  grid = (N*N/NPL column blocks, directions of the chunk).  x-part of the two inverse transforms, hadamard_product
 // (BoltzmannCUDAKernels.cu:62-74) in registers, x-part of the forward transform (CUDABoltzmannOperator.cu:175-178).
 template <int N, typename T, class Ctx>

@@ -172,10 +172,12 @@ struct DevCtx {
 
 template <K kind, int N>
 constexpr int kernel_threads() {
+    if (kind == K::GainInv && pair_tile<N>()) return pair_threads<N>();      // two tiles side by side (N = 32)
     return kind == K::Reduce ? 256 : (is_line_kind(kind) ? Wg<N>::LINE_THREADS : Wg<N>::THREADS);
 }
 template <K kind, int N, typename T>
 constexpr size_t kernel_lds_bytes() {
+    if (kind == K::GainInv && pair_tile<N>()) return pair_lds_bytes<N, T>();
     return kind == K::Reduce ? 0 : (is_line_kind(kind) ? line_lds_bytes<N, T>() : tile_lds_bytes<N, T>());
 }
 
@@ -199,6 +201,7 @@ __global__ void __launch_bounds__((kernel_threads<kind, N>()), (kernel_min_waves
     else if constexpr (kind == K::LineInv) body_line<N, +1, T>(prm, ctx);
     else if constexpr (kind == K::TileFwd) body_tile_c2c<N, -1, T>(prm, ctx);
     else if constexpr (kind == K::TileInv) body_tile_c2c<N, +1, T>(prm, ctx);
+    else if constexpr (kind == K::GainInv && pair_tile<N>()) body_gain_inv_pair<N, T>(prm, ctx);
     else if constexpr (kind == K::GainInv) body_gain_inv<N, T>(prm, ctx);
     else if constexpr (kind == K::GainLine) body_gain_line<N, T>(prm, ctx);
     else if constexpr (kind == K::GainFwd) body_gain_fwd<N, T>(prm, ctx);

@@ -156,6 +156,7 @@ struct EmuBackend {
         else if constexpr (kind == K::LineInv) body_line<N, +1, T>(prm, ctx);
         else if constexpr (kind == K::TileFwd) body_tile_c2c<N, -1, T>(prm, ctx);
         else if constexpr (kind == K::TileInv) body_tile_c2c<N, +1, T>(prm, ctx);
+        else if constexpr (kind == K::GainInv && pair_tile<N>()) body_gain_inv_pair<N, T>(prm, ctx);
         else if constexpr (kind == K::GainInv) body_gain_inv<N, T>(prm, ctx);
         else if constexpr (kind == K::GainLine) body_gain_line<N, T>(prm, ctx);
         else if constexpr (kind == K::GainFwd) body_gain_fwd<N, T>(prm, ctx);
@@ -169,9 +170,11 @@ struct EmuBackend {
 
     template <bfsm::K kind, int N, typename T, class P>
     void launch_n(int gx, int gy, int gz, const P& prm) {
-        const int threads = kind == bfsm::K::Reduce ? 256
+        const bool pair = kind == bfsm::K::GainInv && bfsm::pair_tile<N>();
+        const int threads = pair ? bfsm::pair_threads<N>() : kind == bfsm::K::Reduce ? 256
                             : (bfsm::is_line_kind(kind) ? bfsm::Wg<N>::LINE_THREADS : bfsm::Wg<N>::THREADS);
-        smem.assign(bfsm::is_line_kind(kind) ? bfsm::line_lds_bytes<N, T>() : bfsm::tile_lds_bytes<N, T>(), 0xCD);
+        smem.assign(pair ? bfsm::pair_lds_bytes<N, T>()
+                         : (bfsm::is_line_kind(kind) ? bfsm::line_lds_bytes<N, T>() : bfsm::tile_lds_bytes<N, T>()), 0xCD);
         P copy = prm;
         for (int bz = 0; bz < gz; ++bz)
             for (int by = 0; by < gy; ++by)
