@@ -274,78 +274,50 @@ struct HipBackend {
     void begin_eval() { recs.clear(); pool_next = 0; }
     void mark(int kind, double bytes) { pend_kind = kind; pend_bytes = bytes; }
 
-    template <K kind, int N, typename T, class P>
-    void launch_n(int gx, int gy, int gz, const P& prm) {
-        constexpr int threads = kernel_threads<kind, N>();
-        constexpr size_t lds = kernel_lds_bytes<kind, N, T>();
-        auto fn = bfsm_kernel<kind, N, T, P>;
-        if (lds > 48 * 1024) {   // opt in to a large dynamic-LDS allocation: once per kernel instantiation AND device
-            static std::atomic<unsigned long long> done{0};
-            const unsigned long long bit = 1ull << (device & 63);
-            if (!(done.load(std::memory_order_relaxed) & bit)) {
-                BFSM_NOTE(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                done.fetch_or(bit, std::memory_order_relaxed);
-            }
-        }
-        Rec rec{pend_kind, pend_bytes, nullptr, nullptr};
-        const bool timed = profile && pend_kind >= 0;
-        if (timed) { rec.e0 = next_event(); rec.e1 = next_event(); BFSM_NOTE(hipEventRecord(rec.e0, stream)); }
-        // hipLaunchKernel returns this launch's own status: an earlier, unrelated sticky error of the calling thread
-        // (a failed hipMalloc of another handle, the caller's own HIP calls) is neither blamed on it nor consumed
-        void* args[] = {const_cast<void*>(static_cast<const void*>(&prm))};
-        BFSM_NOTE(hipLaunchKernel(reinterpret_cast<const void*>(fn), dim3((unsigned)gx, (unsigned)gy, (unsigned)gz),
-                                  dim3(threads, 1, 1), args, lds, stream));
-        if (timed) { BFSM_NOTE(hipEventRecord(rec.e1, stream)); recs.push_back(rec); }
-        pend_kind = -1;
-    }
-
-    template <SK kind, typename T, class P>
-    void launch_small(int gx, const P& prm) {
-        launch_any(reinterpret_cast<const void*>(bfsm_small_kernel<kind, T, P>), gx, 1, SMALL_THREADS,
-                   kind == SK::Reduce ? 256 * sizeof(double) : small_lds_bytes<T>(), &prm,
-                   small_attr_done[(int)kind][sizeof(T) == 8]);
-    }
-    std::atomic<unsigned long long> small_attr_done[2][2] = {};
-
-    // common tail of the size-independent launchers: large-LDS opt-in once per device, events, launch status
-    void launch_any(const void* fn, int gx, int gy, int threads, size_t lds, const void* prm, std::atomic<unsigned long long>& done) {
-        if (gx <= 0 || gy <= 0) return;
+    // Common launcher: opts the kernel in to a large dynamic-LDS allocation (once per kernel instantiation and device),
+    // brackets the launch with events when profiling, and takes the launch's OWN status from hipLaunchKernel: an earlier,
+    // unrelated sticky error of the calling thread (a failed hipMalloc of another handle, the caller's own HIP calls) is
+    // neither blamed on this launch nor consumed.
+    void launch_any(const void* fn, int gx, int gy, int gz, int threads, size_t lds, const void* prm,
+                    std::atomic<unsigned long long>& lds_opted_in, size_t lds_limit = 0) {
+        if (gx <= 0 || gy <= 0 || gz <= 0) return;
         if (lds > 48 * 1024) {
             const unsigned long long bit = 1ull << (device & 63);
-            if (!(done.load(std::memory_order_relaxed) & bit)) {
-                BFSM_NOTE(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                done.fetch_or(bit, std::memory_order_relaxed);
+            if (!(lds_opted_in.load(std::memory_order_relaxed) & bit)) {
+                BFSM_NOTE(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_limit ? lds_limit : lds)));
+                lds_opted_in.fetch_or(bit, std::memory_order_relaxed);
             }
         }
         Rec rec{pend_kind, pend_bytes, nullptr, nullptr};
         const bool timed = profile && pend_kind >= 0;
         if (timed) { rec.e0 = next_event(); rec.e1 = next_event(); BFSM_NOTE(hipEventRecord(rec.e0, stream)); }
         void* args[] = {const_cast<void*>(prm)};
-        BFSM_NOTE(hipLaunchKernel(fn, dim3((unsigned)gx, (unsigned)gy, 1), dim3((unsigned)threads, 1, 1), args, lds, stream));
+        BFSM_NOTE(hipLaunchKernel(fn, dim3((unsigned)gx, (unsigned)gy, (unsigned)gz), dim3((unsigned)threads, 1, 1), args, lds, stream));
         if (timed) { BFSM_NOTE(hipEventRecord(rec.e1, stream)); recs.push_back(rec); }
         pend_kind = -1;
     }
 
+    template <K kind, int N, typename T, class P>
+    void launch_n(int gx, int gy, int gz, const P& prm) {
+        static std::atomic<unsigned long long> opted{0};
+        launch_any(reinterpret_cast<const void*>(bfsm_kernel<kind, N, T, P>), gx, gy, gz, kernel_threads<kind, N>(),
+                   kernel_lds_bytes<kind, N, T>(), &prm, opted);
+    }
+
+    // N = 16 whole-direction kernels
+    template <SK kind, typename T, class P>
+    void launch_small(int gx, const P& prm) {
+        static std::atomic<unsigned long long> opted{0};
+        launch_any(reinterpret_cast<const void*>(bfsm_small_kernel<kind, T, P>), gx, 1, 1, SMALL_THREADS,
+                   kind == SK::Reduce ? 256 * sizeof(double) : small_lds_bytes<T>(), &prm, opted);
+    }
+
+    // size-generic path; the LDS need depends on the transformed axis, so the opt-in asks for the whole CU's 160 KiB
     template <GK kind, typename T, class P>
     void launch_gen(int gx, int gy, int threads, size_t lds, const P& prm) {
-        if (gx <= 0 || gy <= 0) return;
-        auto fn = bfsm_gen_kernel<kind, T, P>;
-        if (lds > 48 * 1024) {
-            static std::atomic<unsigned long long> done{0};
-            const unsigned long long bit = 1ull << (device & 63);
-            if (!(done.load(std::memory_order_relaxed) & bit)) {
-                BFSM_NOTE(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                done.fetch_or(bit, std::memory_order_relaxed);
-            }
-        }
-        Rec rec{pend_kind, pend_bytes, nullptr, nullptr};
-        const bool timed = profile && pend_kind >= 0;
-        if (timed) { rec.e0 = next_event(); rec.e1 = next_event(); BFSM_NOTE(hipEventRecord(rec.e0, stream)); }
-        void* args[] = {const_cast<void*>(static_cast<const void*>(&prm))};
-        BFSM_NOTE(hipLaunchKernel(reinterpret_cast<const void*>(fn), dim3((unsigned)gx, (unsigned)gy, 1), dim3((unsigned)threads, 1, 1),
-                                  args, lds, stream));
-        if (timed) { BFSM_NOTE(hipEventRecord(rec.e1, stream)); recs.push_back(rec); }
-        pend_kind = -1;
+        static std::atomic<unsigned long long> opted{0};
+        launch_any(reinterpret_cast<const void*>(bfsm_gen_kernel<kind, T, P>), gx, gy, 1, threads, lds, &prm, opted,
+                   (size_t)160 * 1024);
     }
 
     template <K kind, typename T, class P>
