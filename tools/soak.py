@@ -29,10 +29,31 @@ for mode in ((False, False), (True, False), (True, True)):
     torch.cuda.synchronize()
     print("mode exact=%s hermitian=%s: 600 evaluations, %d mismatching snapshots" % (mode[0], mode[1], bad))
     op.destroy()
+# the other kernel families: whole-direction kernels (N = 16) and the size-generic path (a 48 x 32 x 20 box)
+for shape, n_gl, n_sph in (((16, 16, 16), 8, 32), ((48, 32, 20), 4, 12)):
+    rng = np.random.default_rng(3)
+    fb = torch.from_numpy(rng.random(shape) + 0.1).cuda()
+    Qb = torch.empty_like(fb)
+    op = bfsm.HIPBoltzmannOperator(bfsm.GaussLegendreQuadrature(n_gl, 0, c["R"]), bfsm.SphericalDesign(n_sph), *shape,
+                                   c["gamma"], c["b_gamma"], c["L"])
+    op.initialize()
+    op(Qb, fb)
+    first = Qb.clone()
+    s = torch.cuda.current_stream().cuda_stream
+    bad = 0
+    for i in range(1, 2001):
+        op.computeCollisionAsync(Qb, fb, s)
+        if i % 250 == 0:
+            torch.cuda.synchronize()
+            bad += int(not torch.equal(Qb, first))
+    torch.cuda.synchronize()
+    print("grid %s: 2000 evaluations, %d mismatching snapshots" % (shape, bad))
+    op.destroy()
 torch.cuda.synchronize()
 free0 = torch.cuda.mem_get_info()[0]
 for i in range(20):
-    op = bfsm.HIPBoltzmannOperator(bfsm.GaussLegendreQuadrature(8, 0, c["R"]), bfsm.SphericalDesign(48), 32, 32, 32,
+    nn = (32, 32, 32) if i % 3 else ((16, 16, 16) if i % 2 else (24, 16, 40))
+    op = bfsm.HIPBoltzmannOperator(bfsm.GaussLegendreQuadrature(8, 0, c["R"]), bfsm.SphericalDesign(48), *nn,
                                    c["gamma"], c["b_gamma"], c["L"])
     op.setExactReductions(i % 2 == 1, hermitian=i % 4 == 3)
     op.setMaxBatch(1 + i % 3)
