@@ -10,7 +10,7 @@
 //     beta2 * f_hat (Kernels.cu:126-159)                                         -> load side of the first tail pass
 //     copy_to_complex (Kernels.cu:4-16)                                          -> load side of the first pass of FFT(f)
 // and a deterministic, atomic-free accumulate (atomic_tensor_contraction, Kernels.cu:79-123).  18 array moves per
-// direction instead of 6: a correct fallback for every size (measured 1.0-1.3 TB/s algorithmic), not a tuned path.  Layouts are the reference's own: physical
+// direction instead of 6: a correct fallback for every size (measured 1.2-1.4 TB/s algorithmic), not a tuned path.  Layouts are the reference's own: physical
 // [x][y][z], spectral [lx][ly][lz], z contiguous.
 //
 // Like bfsm_core.hpp the kernel bodies are templates over an execution context, so tests/emu runs the same code on the
@@ -181,31 +181,47 @@ BFSM_HD void body_gen_fft(const GenFftParams<T>& prm, Ctx& ctx) {
     else if (axis == 1) { i0x = col / nz; i0z = col - i0x * nz; base = (size_t)i0x * ny * nz + i0z; ps = (size_t)nz; }
     else { i0x = col / ny; i0y = col - i0x * ny; base = (size_t)col * nz; ps = 1; }
     const size_t in_off = (size_t)b * prm.in_bstride;
-    for (int pt = p0; pt < n; pt += GEN_THREADS / GEN_C) {
-        cx<T> v = {(T)0, (T)0};
-        if (live) {
-            const size_t idx = base + (size_t)pt * ps;
-            if (prm.mode == GEN_REAL) {
-                v.x = (T) static_cast<const double*>(prm.in)[in_off + idx];
-            } else {
-                v = static_cast<const cx<T>*>(prm.in)[in_off + idx];
-                if (prm.mode == GEN_PRODUCT) {
-                    v = cmul(v, prm.in2[in_off + idx]);
-                } else if (prm.mode == GEN_PHASE || prm.mode == GEN_BETA2) {
-                    const int ix = axis == 0 ? pt : i0x, iy = axis == 1 ? pt : i0y, iz = axis == 2 ? pt : i0z;
-                    if (prm.mode == GEN_PHASE) {
-                        const size_t d = (size_t)(prm.dir0 + (b >> 1));
-                        const cx<T> ph = cmul(cmul(prm.phx[d * nx + ix], prm.phy[d * ny + iy]), prm.phz[d * nz + iz]);
-                        v = (b & 1) ? cmulc(v, ph) : cmul(v, ph);
-                    } else {
-                        const int mx = gen_mode(ix, nx), my = gen_mode(iy, ny), mz = gen_mode(iz, nz);
-                        const T b2 = prm.beta2[mx * mx + my * my + mz * mz];
-                        v = {b2 * v.x, b2 * v.y};
-                    }
-                }
+    // the global loads are issued four points at a time before any of them is consumed: the trip count is a run-time
+    // value, and a rolled loop would pay one full memory latency per point
+    constexpr int STEP = GEN_THREADS / GEN_C, CH = 4;
+    for (int pc = p0; pc < n; pc += CH * STEP) {
+        cx<T> vin[CH], vin2[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int pt = pc + i * STEP;
+            vin[i] = {(T)0, (T)0};
+            vin2[i] = {(T)1, (T)0};
+            if (live && pt < n) {
+                const size_t idx = base + (size_t)pt * ps;
+                if (prm.mode == GEN_REAL) vin[i].x = (T) static_cast<const double*>(prm.in)[in_off + idx];
+                else vin[i] = static_cast<const cx<T>*>(prm.in)[in_off + idx];
+                if (prm.mode == GEN_PRODUCT) vin2[i] = prm.in2[in_off + idx];
             }
         }
-        buf0[pt * GEN_LS + cl] = v;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int pt = pc + i * STEP;
+            if (pt < n) {
+                cx<T> v = vin[i];
+                if (live) {
+                    if (prm.mode == GEN_PRODUCT) {
+                        v = cmul(v, vin2[i]);
+                    } else if (prm.mode == GEN_PHASE || prm.mode == GEN_BETA2) {
+                        const int ix = axis == 0 ? pt : i0x, iy = axis == 1 ? pt : i0y, iz = axis == 2 ? pt : i0z;
+                        if (prm.mode == GEN_PHASE) {
+                            const size_t d = (size_t)(prm.dir0 + (b >> 1));
+                            const cx<T> ph = cmul(cmul(prm.phx[d * nx + ix], prm.phy[d * ny + iy]), prm.phz[d * nz + iz]);
+                            v = (b & 1) ? cmulc(v, ph) : cmul(v, ph);
+                        } else {
+                            const int mx = gen_mode(ix, nx), my = gen_mode(iy, ny), mz = gen_mode(iz, nz);
+                            const T b2 = prm.beta2[mx * mx + my * my + mz * mz];
+                            v = {b2 * v.x, b2 * v.y};
+                        }
+                    }
+                }
+                buf0[pt * GEN_LS + cl] = v;
+            }
+        }
     }
     ctx.sync();
     cx<T>* src = buf0;
