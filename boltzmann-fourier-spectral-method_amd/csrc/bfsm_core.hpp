@@ -852,6 +852,23 @@ BFSM_HD void hermitian_lines_load(cx<T>* a, cx<T>* b, const cx<T>* A1, const cx<
     }
 }
 
+// The same for ONE array (used where the registers do not hold both lines of a direction at once: N = 128).
+template <int N, typename T, class Ctx>
+BFSM_HD void hermitian_line_load1(cx<T>* a, const cx<T>* A1, int colrow, unsigned pl, int p, int u, cx<T>* lds, Ctx& ctx) {
+    constexpr int E = Wg<N>::E, TT = Wg<N>::T, MS = E / 2, LS = Wg<N>::NPL + 1, H = N / 2;
+    constexpr bool UNI = Wg<N>::NPL % 64 == 0;
+#pragma unroll
+    for (int m = 0; m < MS; ++m) a[m] = ctx.template ld_stream_at<UNI>(A1 + (size_t)(u + TT * m) * N * N + colrow, pl);
+    if (u == 0) a[MS] = ctx.template ld_stream_at<UNI>(A1 + (size_t)H * N * N + colrow, pl);
+    ctx.sync();
+#pragma unroll
+    for (int m = 0; m < MS; ++m) ctx.lds_st(lds + (u + TT * m) * LS + p, a[m]);
+    ctx.sync();
+#pragma unroll
+    for (int m = MS; m < E; ++m)
+        if (m > MS || u != 0) a[m] = ctx.lds_ld(lds + (N - (u + TT * m)) * LS + p);
+}
+
 template <int N, typename T, class Ctx>
 BFSM_HD void hermitian_line_fix(cx<T>* v, const cx<T>* R, int y, int z0, int p, int u, Ctx& ctx) {
     constexpr int E = Wg<N>::E, TT = Wg<N>::T, NQ = N / 2 - 1, H = N / 2, MS = E / 2;
@@ -888,11 +905,20 @@ BFSM_HD void body_gain_line_acc_h(const GainLineAccHParams<T>& prm, Ctx& ctx) {
         const size_t abase = (size_t)ctx.bz() * prm.a_bstride + (size_t)d * NH * N * N;
         const cx<T>* R = prm.r + (size_t)ctx.bz() * prm.r_bstride + (size_t)d * 4 * NQ * N;
         cx<T> a[E], b[E];
-        hermitian_lines_load<N, T>(a, b, prm.a1 + abase, prm.a2 + abase, colrow, pl, p, u, lds, ctx);
-        hermitian_line_fix<N, T>(a, R, y, z0, p, u, ctx);
-        fft_line_np<N, NPL, +1, T>(a, lds, p, u, twr, ctx);
-        hermitian_line_fix<N, T>(b, R + (size_t)2 * NQ * N, y, z0, p, u, ctx);
-        fft_line_np<N, NPL, +1, T>(b, lds, p, u, twr, ctx);
+        if constexpr (N >= 128) {      // 16 points per thread: one line at a time keeps the kernel inside 128 VGPRs
+            hermitian_line_load1<N, T>(a, prm.a1 + abase, colrow, pl, p, u, lds, ctx);
+            hermitian_line_fix<N, T>(a, R, y, z0, p, u, ctx);
+            fft_line_np<N, NPL, +1, T>(a, lds, p, u, twr, ctx);
+            hermitian_line_load1<N, T>(b, prm.a2 + abase, colrow, pl, p, u, lds, ctx);
+            hermitian_line_fix<N, T>(b, R + (size_t)2 * NQ * N, y, z0, p, u, ctx);
+            fft_line_np<N, NPL, +1, T>(b, lds, p, u, twr, ctx);
+        } else {
+            hermitian_lines_load<N, T>(a, b, prm.a1 + abase, prm.a2 + abase, colrow, pl, p, u, lds, ctx);
+            hermitian_line_fix<N, T>(a, R, y, z0, p, u, ctx);
+            fft_line_np<N, NPL, +1, T>(a, lds, p, u, twr, ctx);
+            hermitian_line_fix<N, T>(b, R + (size_t)2 * NQ * N, y, z0, p, u, ctx);
+            fft_line_np<N, NPL, +1, T>(b, lds, p, u, twr, ctx);
+        }
         const T w = prm.dirw[prm.dir0 + d];
 #pragma unroll
         for (int m = 0; m < E; ++m) {
