@@ -158,6 +158,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-exact", action="store_true", help="skip the extra opt-in exact-reduction measurement")
     ap.add_argument("--no-extras", action="store_true", help="skip the blocking_call / overlapped side measurements")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="extra K-step loops after the headline loop; their median / min / max go to the `repeats` key")
     ap.add_argument("--rehearsal", action="store_true",
                     help="CPU plumbing rehearsal of the N>1 launch path (no GPU, no measurement): the ranks are started, "
                          "form a gloo group, shard the directions and run the collective with the tests' host emulator "
@@ -304,6 +306,15 @@ def main():
 
     ms_per_step = 1e3 * elapsed / args.steps
     evals_per_s = args.steps / elapsed
+    # `value` is the driver's K steps above.  One K-step sample of a few tens of ms moves with the chip's clock / power
+    # state; the spread of further identical K-step loops is reported beside it (never as `value`).
+    repeats = None
+    if args.repeats > 0:
+        import statistics
+        rates = sorted(args.steps / timed(op, "inorder") for _ in range(args.repeats))
+        repeats = {"n": args.repeats, "steps_each": args.steps, "median": statistics.median(rates), "min": rates[0],
+                   "max": rates[-1], "unit": "evals/s",
+                   "note": "further K-step loops after the headline loop, same handle, same timing brackets"}
     cbytes = 16.0 if prec == 64 else 8.0
     alg_bytes = (6.0 * B + 9.0) * nv ** 3 * cbytes            # whole evaluation, all GPUs
     alg_gbps = alg_bytes / (elapsed / args.steps) / 1e9
@@ -331,9 +342,13 @@ def main():
         for _ in range(2):
             profiled_eval()
         torch.cuda.synchronize()
-        reps, acc = 5, None
+        # Same regime as the timed loop: evaluations queued back to back, no host synchronisation between them; the
+        # handle keeps the events of the LAST evaluation of a burst, which ran directly behind its predecessors (a
+        # kernel that starts after an idle gap reads up to 15 % longer, so sum(per_kernel) would exceed ms_per_step).
+        reps, acc, burst = 5, None, 3
         for _ in range(reps):
-            profiled_eval()
+            for _ in range(burst):
+                profiled_eval()
             torch.cuda.synchronize()
             cn = opp.counters()
             cur = [(cn.kernel_ms[i], cn.kernel_alg_bytes[i], cn.kernel_launches[i]) for i in range(len(bfsm.KERNEL_NAMES))]
@@ -363,12 +378,16 @@ def main():
                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                     "alg_bytes_per_launch": nbytes / max(launches, 1), "avg_launch_ms": ms / max(launches, 1),
                     "launches_per_eval": launches // reps,
+                    "per_kernel_regime": f"HIP events of the last of {burst} evaluations queued back to back, mean of {reps} bursts",
+                    "per_kernel_sum_ms": sum(a[0] for a in acc) / reps,
                     "per_kernel": {bfsm.KERNEL_NAMES[i]: {"ms_per_eval": acc[i][0] / reps,
                                                           "alg_GBps": (acc[i][1] / (acc[i][0] * 1e-3) / 1e9) if acc[i][0] > 0 else 0.0}
                                    for i in range(len(acc))}}
 
     # Opt-in exact work reductions: same Q to rounding, ~1/3 of the FFT work.  Reported beside the
-    # headline, never as the headline: `value` above always evaluates every direction with its own three FFTs.
+    # headline, never as the headline: `value` above always evaluates every direction -- its own two inverse 3-D
+    # transforms, product and x part of the forward transform, every array written and read once per direction (6 array
+    # passes); only the (y,z) part of the forward transform acts on a segment's weighted sum (config.kc_sum_before_transform).
     exact = None
     if not args.no_exact:
         ope = make(False, exact=True)
@@ -412,7 +431,7 @@ def main():
             "frac_of_measured_copy_ceiling": alg_gbps / (HBM_COPY_CEILING_GBPS * world),
             "alg_bytes_per_eval": alg_bytes,
             "roofline": roofline, "cpu_baseline": cpu, "blocking_call": blocking, "overlapped": overlapped,
-            "exact_reductions": exact,
+            "exact_reductions": exact, "repeats": repeats,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -358,7 +358,13 @@ struct bfsm_plan {
     std::string err;
     bfsm_counters counters{};
     bool full_shard = true;
-    std::vector<hipStream_t> pending;   // streams this handle has enqueued on since its last bfsm_synchronize
+    // Work this handle has enqueued since its last bfsm_synchronize: one handle-owned event per distinct stream, recorded
+    // behind the last call on that stream.  The stream value is kept as a KEY only (compared, never passed to HIP again),
+    // so a stream the caller has destroyed in the meantime is harmless.
+    struct Pending { hipStream_t key; hipEvent_t ev; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> spare_events;
+    static constexpr size_t MAX_PENDING = 64;
 };
 
 static thread_local std::string g_create_error;
@@ -476,19 +482,39 @@ int bfsm_create(const bfsm_desc* desc, bfsm_handle* out) {
     return rc;
 }
 
-// Common prologue of the entry points (after the DeviceGuard): remember the stream of this call.
+// Common prologue of the entry points (after the DeviceGuard): the stream of this call.
 static int enter(bfsm_plan* h, const DeviceGuard& g, void* stream) {
     if (g.err != hipSuccess) return fail(h, BFSM_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(g.err));
     h->be.stream = (hipStream_t)stream;
-    bool seen = false;
-    for (hipStream_t s : h->pending) seen = seen || s == h->be.stream;
-    if (!seen) {
-        if (h->pending.size() >= 16) {      // bounded: retire the oldest stream before remembering another one
-            (void)hipStreamSynchronize(h->pending.front());
+    return BFSM_OK;
+}
+
+// Common epilogue of the entry points that enqueue work: the launch status of this call, then one event record behind
+// the call so that bfsm_synchronize can wait for it without ever touching the caller's stream handle again.  Never
+// blocks and never queries (an *_async entry point only enqueues); nothing is recorded while the stream is being
+// captured into a graph (a captured launch does not run, and a captured event could not be waited for).
+static int leave(bfsm_plan* h, const char* where) {
+    int rc = check_hip(h, where);
+    if (rc) return rc;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(h->be.stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    if (cap != hipStreamCaptureStatusNone) return BFSM_OK;
+    bfsm_plan::Pending* slot = nullptr;
+    for (auto& pe : h->pending) if (pe.key == h->be.stream) slot = &pe;
+    if (!slot) {
+        if (h->pending.size() >= bfsm_plan::MAX_PENDING) {   // bounded: stop tracking the least recently added stream
+            h->spare_events.push_back(h->pending.front().ev);
             h->pending.erase(h->pending.begin());
         }
-        h->pending.push_back(h->be.stream);
+        hipEvent_t ev = nullptr;
+        if (!h->spare_events.empty()) { ev = h->spare_events.back(); h->spare_events.pop_back(); }
+        else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess)
+            return fail(h, BFSM_ERR_HIP, std::string("hipEventCreateWithFlags failed (during ") + where + ")");
+        h->pending.push_back({h->be.stream, ev});
+        slot = &h->pending.back();
     }
+    hipError_t e = hipEventRecord(slot->ev, h->be.stream);
+    if (e != hipSuccess) return fail(h, BFSM_ERR_HIP, std::string("hipEventRecord: ") + hipGetErrorString(e) + " (during " + where + ")");
     return BFSM_OK;
 }
 
@@ -501,7 +527,7 @@ int bfsm_gain_partial(bfsm_handle h, const double* f_dev, void* stream) {
         if (!f_dev) return fail(h, BFSM_ERR_INVALID, "null f");
         h->be.begin_eval();
         h->with([&](auto& p) { p.gain_partial(f_dev); });
-        return check_hip(h, "bfsm_gain_partial");
+        return leave(h, "bfsm_gain_partial");
     )
 }
 
@@ -513,7 +539,7 @@ int bfsm_finish(bfsm_handle h, double* Q_dev, const double* f_dev, void* stream)
         if (rc) return rc;
         if (!f_dev || !Q_dev) return fail(h, BFSM_ERR_INVALID, "null f or Q");
         h->with([&](auto& p) { p.finish(Q_dev, f_dev); });
-        return check_hip(h, "bfsm_finish");
+        return leave(h, "bfsm_finish");
     )
 }
 
@@ -525,7 +551,7 @@ int bfsm_finish_partial(bfsm_handle h, double* Q_dev, const double* f_dev, int w
         if (rc) return rc;
         if (!f_dev || !Q_dev) return fail(h, BFSM_ERR_INVALID, "null f or Q");
         h->with([&](auto& p) { p.finish(Q_dev, f_dev, with_loss != 0); });
-        return check_hip(h, "bfsm_finish_partial");
+        return leave(h, "bfsm_finish_partial");
     )
 }
 
@@ -545,9 +571,13 @@ int bfsm_collide_batch_partial_async(bfsm_handle h, double* Q_dev, const double*
             for (int i = 0; i < n_batch; ++i)
                 h->with([&](auto& p) { p.gain_partial(f_dev + (size_t)i * h->G); p.finish(Q_dev + (size_t)i * h->G, f_dev + (size_t)i * h->G, with_loss != 0); });
         } else {
-            h->with([&](auto& p) { const bool fu = p.fuse_reduce(); p.gain_partial(f_dev, n_batch, !fu); p.finish(Q_dev, f_dev, with_loss != 0, n_batch, fu); });
+            h->with([&](auto& p) {
+                // a batch of one on a single-evaluation N = 16 handle takes the same whole-direction kernels as bfsm_collide
+                if (p.small_path(n_batch)) { p.collide_small(Q_dev, f_dev, with_loss != 0); return; }
+                const bool fu = p.fuse_reduce(); p.gain_partial(f_dev, n_batch, !fu); p.finish(Q_dev, f_dev, with_loss != 0, n_batch, fu);
+            });
         }
-        return check_hip(h, "bfsm_collide_batch");
+        return leave(h, "bfsm_collide_batch");
     )
 }
 
@@ -585,7 +615,7 @@ int bfsm_collide_partial_async(bfsm_handle h, double* Q_dev, const double* f_dev
             p.gain_partial(f_dev, 1, !fu);
             p.finish(Q_dev, f_dev, with_loss != 0, 1, fu);
         });
-        return check_hip(h, "bfsm_collide_partial");
+        return leave(h, "bfsm_collide_partial");
     )
 }
 
@@ -600,10 +630,15 @@ int bfsm_synchronize(bfsm_handle h) {
     BFSM_GUARDED(h,
         DeviceGuard g(h->desc.device);
         hipError_t e = g.err;
-        for (hipStream_t s : h->pending)    // every stream a call on this handle was given, not only the last one
-            if (e == hipSuccess) e = hipStreamSynchronize(s);
-        if (e != hipSuccess) return fail(h, BFSM_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+        // every stream a call on this handle was given, not only the last one; the list is cleared whatever happens, so
+        // one failure does not poison the later calls
+        for (auto& pe : h->pending) {
+            const hipError_t ei = (g.err == hipSuccess) ? hipEventSynchronize(pe.ev) : g.err;
+            if (e == hipSuccess) e = ei;
+            h->spare_events.push_back(pe.ev);
+        }
         h->pending.clear();
+        if (e != hipSuccess) { (void)hipGetLastError(); return fail(h, BFSM_ERR_HIP, std::string("bfsm_synchronize: ") + hipGetErrorString(e)); }
         return BFSM_OK;
     )
 }
@@ -629,7 +664,7 @@ int bfsm_fft3d(bfsm_handle h, void* data_dev, int batch, int sign) {
         else if (h->p32) h->p32->fft3d((bfsm::cx<float>*)data_dev, batch, sign);
         else if (h->g64) h->g64->fft3d((bfsm::cx<double>*)data_dev, batch, sign);
         else h->g32->fft3d((bfsm::cx<float>*)data_dev, batch, sign);
-        rc = check_hip(h, "bfsm_fft3d");
+        rc = leave(h, "bfsm_fft3d");
         if (rc) return rc;
         return bfsm_synchronize(h);
     )
@@ -648,8 +683,8 @@ int bfsm_get_counters(bfsm_handle h, bfsm_counters* out) {
     if (h->be.profile && !h->be.recs.empty()) {
         DeviceGuard g(h->desc.device);
         hipError_t e = g.err;
-        if (e == hipSuccess) e = hipStreamSynchronize(h->be.stream);
-        if (e != hipSuccess) return fail(h, BFSM_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+        if (e == hipSuccess) e = hipEventSynchronize(h->be.recs.back().e1);   // the handle's own event, not the caller's stream
+        if (e != hipSuccess) return fail(h, BFSM_ERR_HIP, std::string("hipEventSynchronize: ") + hipGetErrorString(e));
         for (const auto& r : h->be.recs) {
             float ms = 0.f;
             e = hipEventElapsedTime(&ms, r.e0, r.e1);
@@ -674,6 +709,8 @@ int bfsm_destroy(bfsm_handle h) {
     if (h->g64) { h->g64->destroy(); delete h->g64; }
     if (h->g32) { h->g32->destroy(); delete h->g32; }
     h->be.destroy_events();
+    for (auto& pe : h->pending) (void)hipEventDestroy(pe.ev);
+    for (hipEvent_t ev : h->spare_events) (void)hipEventDestroy(ev);
     delete h;
     return BFSM_OK;
 }

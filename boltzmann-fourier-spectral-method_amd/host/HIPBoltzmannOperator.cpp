@@ -67,6 +67,12 @@ void BoltzmannOperator<HIP_Backend>::collidePartial(double* Q, const double* f_i
     check(bfsm_collide_partial_async(handle_, Q, f_in, with_loss ? 1 : 0, stream), "collidePartial");
 }
 
+int BoltzmannOperator<HIP_Backend>::collidePartialStatus(double* Q, const double* f_in, bool with_loss, void* stream) noexcept {
+    return bfsm_collide_partial_async(handle_, Q, f_in, with_loss ? 1 : 0, stream);
+}
+
+const char* BoltzmannOperator<HIP_Backend>::lastError() const noexcept { return bfsm_last_error(handle_); }
+
 void* BoltzmannOperator<HIP_Backend>::qhatBuffer(size_t* n_elems, int* precision) const {
     return bfsm_qhat_buffer(handle_, n_elems, precision);
 }

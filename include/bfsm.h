@@ -15,8 +15,10 @@
  *     they reuse the scratch.  Different handles are independent and may be driven from different threads / streams.
  *   - every call makes the handle's device current for its own duration and restores the calling thread's current
  *     device before it returns.
- *   - the *_async entry points only enqueue kernels on the given stream (no allocation, no synchronisation), so
- *     after one evaluation outside a capture they can be captured into a HIP graph.
+ *   - the *_async entry points only enqueue kernels on the given stream (no allocation, no synchronisation, no
+ *     stream or event query), so after one evaluation outside a capture they can be captured into a HIP graph.  Outside
+ *     a capture each call also records one handle-owned event behind its work (what bfsm_synchronize waits for); the
+ *     caller's stream handle is never used after the call returns, so the caller may destroy the stream at any time.
  *   - functions never throw and never exit: they return BFSM_OK or an error code, and bfsm_last_error() returns a
  *     human-readable message (the reference prints and std::exit()s, CUDABoltzmannOperator.hpp:20-38; the C++
  *     wrapper restores that behaviour).
@@ -54,7 +56,13 @@ enum {
      *       directions per radial node are evaluated, with doubled weight; otherwise this part is skipped;
      *  (ii) FFT linearity: the products of all directions of a radial node are summed in physical space and
      *       forward-transformed once, instead of one forward FFT per direction.
-     * The default (flag clear) evaluates every direction with its own three FFTs, like the reference. */
+     * The default (flag clear) evaluates every direction: its own two inverse 3-D transforms, its own product and the
+     * x part of its own forward transform; the (y,z) part of the forward transform is applied once to the weighted sum
+     * of a run of directions that share a radial node (linearity; every array is still written and read once per
+     * direction: 6 array passes per direction).  Build with -DBFSM_KC_PER_DIRECTION for one (y,z)
+     * forward transform per direction (the reference's literal loop, FFTWBoltzmannOperator.cpp:249).
+     * On boxes served by the size-generic path (see bfsm_desc::nvx) this flag and BFSM_FLAG_HERMITIAN are accepted and
+     * have no effect (the results are the same by definition; bfsm_counters::exact_reductions reports 0). */
     BFSM_FLAG_EXACT_REDUCTIONS = 2,
     /* Additional exact reduction on top of BFSM_FLAG_EXACT_REDUCTIONS (invalid without it): f is real, so the
      * half-transformed arrays satisfy A'[-lx] = conj A'[lx] up to the three Nyquist planes; only the planes
@@ -135,7 +143,9 @@ int bfsm_collide_async(bfsm_handle h, double* Q_dev, const double* f_dev, void* 
 /* Batch of distributions (new functionality): f_dev and Q_dev hold n_batch <= desc.max_batch
  * consecutive N^3 arrays; every kernel launch covers the whole batch (one more grid dimension), so the quadrature
  * tables are shared and small grids (N = 16, 32) fill the GPU.  Member i of the result is bitwise identical to
- * bfsm_collide on member i alone.  Batches are independent: on several GPUs they shard without any collective. */
+ * bfsm_collide on member i alone ON THE SAME HANDLE (a handle created with max_batch > 1 keeps one set of kernels for
+ * single and batched calls; a batch of one on a max_batch <= 1 handle is bfsm_collide itself).  Batches are
+ * independent: on several GPUs they shard without any collective. */
 int bfsm_collide_batch(bfsm_handle h, double* Q_dev, const double* f_dev, int n_batch);
 int bfsm_collide_batch_async(bfsm_handle h, double* Q_dev, const double* f_dev, int n_batch, void* stream);
 /* Batch x direction shard in one call (the two data-parallel axes composed): the handle may own any shard of the
@@ -170,8 +180,10 @@ int bfsm_collide_partial_async(bfsm_handle h, double* Q_dev, const double* f_dev
  * library's spectral layout [lx][lz][ly]); the buffer the collective must sum in place. */
 void* bfsm_qhat_buffer(bfsm_handle h, size_t* n_elems, int* precision);
 
-/* Blocks until everything enqueued by this handle has completed: every stream that was passed to one of its entry
- * points since the previous bfsm_synchronize is waited for, not only the most recent one. */
+/* Blocks until everything enqueued by this handle has completed: the work of every stream that was passed to one of
+ * its entry points since the previous bfsm_synchronize is waited for (through events the handle recorded itself), not
+ * only the most recent one; the 64 most recently added distinct streams are tracked.  The list is cleared whether or
+ * not the wait succeeds, so a failure does not affect later calls. */
 int bfsm_synchronize(bfsm_handle h);
 
 /* Batched 3-D complex transform with the library's own kernels (counterpart of the cufftPlanMany plan,

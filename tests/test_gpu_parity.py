@@ -558,6 +558,19 @@ def test_full_size_field_matches_oracle(torch_cuda, oracle, nv, n_gl, n_sph, mod
     assert np.abs(got - ref).max() <= TOL64 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("mode", ["faithful", "exact", "hermitian"])
+def test_full_size_field_fp32_n128_matches_oracle(torch_cuda, oracle, mode):
+    """The single-precision variant of config 5's grid on the same 2 x 48-direction quadrature and the same cached
+    oracle field as the fp64 case above (96 directions instead of the 24 of test_n128_fp32_matches_oracle), whole
+    field, all three modes, at the fp32 tolerance."""
+    import bfsm
+    f_h, ref = _full_ref(oracle, 128, 2, 48)
+    op = _make(bfsm, 128, 2, 48, 32, exact=(mode != "faithful"), hermitian=(mode == "hermitian"))
+    got = _collide(torch_cuda, op, f_h)
+    op.destroy()
+    assert np.abs(got - ref).max() <= TOL32 * np.abs(ref).max()
+
+
 def test_failed_create_does_not_poison_the_next_handle(torch_cuda):
     """A create that fails with BFSM_ERR_NOMEM (scratch for an absurd batch) must not leave a sticky HIP error behind
     that the next, healthy handle's first launch would be blamed for: the documented recovery is to retry smaller."""
@@ -944,16 +957,106 @@ def test_synchronize_waits_for_every_stream_the_handle_used(torch_cuda, oracle):
     ref = _oracle(oracle, f_h, n_gl, n_sph)
     op = _make(bfsm, nv, n_gl, n_sph)
     f = torch.from_numpy(f_h).cuda()
+    f2 = 2.0 * f                           # produced on torch's current stream ...
     Qa, Qb = torch.zeros_like(f), torch.zeros_like(f)
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
-    torch.cuda.synchronize()
+    torch.cuda.synchronize()               # ... and complete before s1 / s2 read it
     op.computeCollisionAsync(Qa, f, s1.cuda_stream)
     ev = torch.cuda.Event()
     ev.record(s1)
     s2.wait_event(ev)                      # same handle, same scratch: the second call is ordered behind the first
-    op.computeCollisionAsync(Qb, 2.0 * f, s2.cuda_stream)
+    op.computeCollisionAsync(Qb, f2, s2.cuda_stream)
     op.synchronize()                       # must cover s1 AND s2
     a, b = Qa.cpu().numpy(), Qb.cpu().numpy()
     assert np.abs(a - ref).max() <= TOL64 * np.abs(ref).max()
     assert np.abs(b - 4.0 * ref).max() <= TOL64 * np.abs(4.0 * ref).max()
     op.destroy()
+
+
+def _hip_runtime():
+    """libamdhip64 through ctypes: raw streams that can really be destroyed (torch's streams come from a pool)."""
+    import ctypes
+    rt = ctypes.CDLL("libamdhip64.so")
+    rt.hipStreamCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+    rt.hipStreamCreate.restype = ctypes.c_int
+    rt.hipStreamDestroy.argtypes = [ctypes.c_void_p]
+    rt.hipStreamDestroy.restype = ctypes.c_int
+    rt.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+    rt.hipStreamSynchronize.restype = ctypes.c_int
+    return rt
+
+
+def test_a_destroyed_stream_does_not_break_the_handle(torch_cuda, oracle):
+    """include/bfsm.h: the caller's stream handle is never used after an entry point returns.  A side stream is
+    destroyed between an async call and bfsm_synchronize (with and without the caller's own wait in between): the
+    synchronize returns BFSM_OK, the result is complete, and the next blocking call on the handle works."""
+    import ctypes
+    import bfsm
+    torch = torch_cuda
+    rt = _hip_runtime()
+    nv, n_gl, n_sph = 32, 4, 12
+    f_h = bfsm.perturbed_input(bfsm.bkw_solution(nv)[0])
+    ref = _oracle(oracle, f_h, n_gl, n_sph)
+    op = _make(bfsm, nv, n_gl, n_sph)
+    f = torch.from_numpy(f_h).cuda()
+    torch.cuda.synchronize()
+    for wait_first in (True, False):
+        Q = torch.zeros_like(f)
+        torch.cuda.synchronize()
+        s = ctypes.c_void_p()
+        assert rt.hipStreamCreate(ctypes.byref(s)) == 0
+        op.computeCollisionAsync(Q, f, s.value)
+        if wait_first:
+            assert rt.hipStreamSynchronize(s) == 0
+        assert rt.hipStreamDestroy(s) == 0          # HIP lets queued work finish; the handle value is dead from here on
+        op.synchronize()                            # BFSM_OK (raises otherwise): waits on the handle's own event
+        assert np.abs(Q.cpu().numpy() - ref).max() <= TOL64 * np.abs(ref).max()
+        Q2 = torch.zeros_like(f)
+        op(Q2, f)                                   # blocking call: bfsm_collide -> bfsm_synchronize
+        assert np.array_equal(Q2.cpu().numpy(), Q.cpu().numpy())
+    op.destroy()
+
+
+def test_async_calls_on_many_streams_never_block(torch_cuda, oracle):
+    """More distinct streams than the handle tracks (64) in a row, each destroyed right after its call: no entry point
+    fails or synchronises a dead stream, and a final bfsm_synchronize returns BFSM_OK."""
+    import ctypes
+    import bfsm
+    torch = torch_cuda
+    rt = _hip_runtime()
+    nv, n_gl, n_sph = 16, 2, 6
+    f_h = bfsm.perturbed_input(bfsm.bkw_solution(nv)[0])
+    ref = _oracle(oracle, f_h, n_gl, n_sph)
+    op = _make(bfsm, nv, n_gl, n_sph)
+    f = torch.from_numpy(f_h).cuda()
+    Q = torch.zeros_like(f)
+    torch.cuda.synchronize()
+    live = []
+    for i in range(80):
+        s = ctypes.c_void_p()
+        assert rt.hipStreamCreate(ctypes.byref(s)) == 0
+        live.append(s)                              # 80 distinct handle values alive at once
+    for s in live:
+        op.computeCollisionAsync(Q, f, s.value)
+        assert rt.hipStreamSynchronize(s) == 0      # calls on one handle must be ordered: here by the host
+    for s in live:
+        assert rt.hipStreamDestroy(s) == 0
+    op.synchronize()
+    assert np.abs(Q.cpu().numpy() - ref).max() <= TOL64 * np.abs(ref).max()
+    op.destroy()
+
+
+def test_batch_of_one_equals_a_single_evaluation_bitwise(torch_cuda):
+    """include/bfsm.h: a batch member is bitwise the single evaluation on the same handle -- including the N = 16
+    single-evaluation handle, whose bfsm_collide runs on the whole-direction kernels (a batch of one takes them too)."""
+    import bfsm
+    torch = torch_cuda
+    for nv, n_gl, n_sph in ((16, 4, 12), (32, 2, 12)):
+        f_h = bfsm.perturbed_input(bfsm.bkw_solution(nv)[0])
+        f = torch.from_numpy(f_h).cuda().reshape(-1)
+        op = _make(bfsm, nv, n_gl, n_sph)
+        Q1, Qb = torch.empty_like(f), torch.empty_like(f)
+        op(Q1, f)
+        op.computeCollisionBatch(Qb, f, 1)
+        assert np.array_equal(Q1.cpu().numpy(), Qb.cpu().numpy())
+        op.destroy()

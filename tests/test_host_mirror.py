@@ -29,3 +29,25 @@ def test_cpp_host_mirror(tmp_path):
                          timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all host-mirror checks passed" in out.stdout
+
+
+import pytest
+
+
+@pytest.mark.parametrize("sanitizer", ["none", "thread"])
+def test_multigpu_operator_choreography_with_p_gt_1(tmp_path, sanitizer):
+    """The thread choreography of BoltzmannOperator<HIP_MultiGPU_Backend> (host/Collisions/detail/MultiGpuCore.hpp, the
+    same template the HIP + RCCL operator instantiates) driven on the CPU with P = 1, 2, 3, 8 device threads, 100
+    back-to-back calls each, an in-process stand-in for the devices and the two collectives: the sum over the shards
+    equals the single-device result bit for bit; initialize() twice; setDevices() after initialize(); a parked team
+    wakes up.  Second build: the same under ThreadSanitizer (any data race fails the run)."""
+    exe = str(tmp_path / "test_multigpu_choreography")
+    flags = ["-fsanitize=thread"] if sanitizer == "thread" else []
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-pthread"] + flags +
+                          ["-I", os.path.join(PKG, "host"), "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "host", "test_multigpu_choreography.cpp"),
+                           os.path.join(PKG, "host", "Quadratures", "SphericalDesign.cpp"), "-o", exe])
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 exitcode=66")
+    out = subprocess.run([exe, os.path.join(PKG, "data", "sph_design")], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "multi-GPU choreography checks passed" in out.stdout and "ThreadSanitizer" not in out.stderr
