@@ -65,12 +65,31 @@ BFSM_HD constexpr double cos16(int j) {
 }
 BFSM_HD constexpr double sin16(int j) { return cos16(j + 12); }  // sin(a) = cos(a - pi/2) = cos(a + 3pi/2)
 
+// Fused-multiply-add helper (one v_fma on the device; contraction is not left to the optimiser's discretion).
+template <typename T> BFSM_HD T fmad(T a, T b, T c) { return __builtin_fma(a, b, c); }
+template <> BFSM_HD float fmad<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// Twiddled radix-2 butterfly  (a, b) <- (a + w b, a - w b),  w = (c, s), in SIX fused multiply-adds instead of a
+// complex multiply (4) plus add / subtract (4):   p = a + w b  takes two chained FMAs per component, and the other
+// output is 2 a - p (one FMA per component).  Rounding stays at the level of the plain form (one extra rounding of a
+// quantity no larger than |a| + |b|).
+template <typename T> BFSM_HD void bfly_tw(cx<T>& a, cx<T>& b, T c, T s) {
+    const T px = fmad(-b.y, s, fmad(b.x, c, a.x));
+    const T py = fmad(b.x, s, fmad(b.y, c, a.y));
+    b = {fmad((T)2, a.x, -px), fmad((T)2, a.y, -py)};
+    a = {px, py};
+}
+
 // In-register DFT of R points, natural order in and out, unnormalised.
 // SGN = -1: forward (exp(-i...)), SGN = +1: backward -- the FFTW_FORWARD / FFTW_BACKWARD convention.
+// Radix-2 decimation in time; butterflies with a non-trivial twiddle use bfly_tw (16 points: 148 operations).
 template <int R, int SGN, typename T>
 struct SmallDft {
     static BFSM_HD void run(cx<T>* a) {
         static_assert(R == 4 || R == 8 || R == 16, "radix");
+#ifdef BFSM_KO_DFT      // knock-out builds (tools only): timing experiments, wrong results
+        return;
+#endif
         cx<T> e[R / 2], o[R / 2];
 #pragma unroll
         for (int k = 0; k < R / 2; ++k) {
@@ -81,18 +100,20 @@ struct SmallDft {
         SmallDft<R / 2, SGN, T>::run(o);
 #pragma unroll
         for (int k = 0; k < R / 2; ++k) {
-            cx<T> t;
             const int j = k * (16 / R);  // angle 2*pi*k/R in sixteenths of a turn
             if (j == 0) {
-                t = o[k];
+                a[k] = cadd(e[k], o[k]);
+                a[k + R / 2] = csub(e[k], o[k]);
             } else if (j == 4) {
-                t = rot90<SGN>(o[k]);
+                const cx<T> t = rot90<SGN>(o[k]);
+                a[k] = cadd(e[k], t);
+                a[k + R / 2] = csub(e[k], t);
             } else {
-                const T c = (T)cos16(j), s = (T)(SGN * sin16(j));
-                t = {o[k].x * c - o[k].y * s, o[k].x * s + o[k].y * c};
+                cx<T> x = e[k], y = o[k];
+                bfly_tw(x, y, (T)cos16(j), (T)(SGN * sin16(j)));
+                a[k] = x;
+                a[k + R / 2] = y;
             }
-            a[k] = cadd(e[k], t);
-            a[k + R / 2] = csub(e[k], t);
         }
     }
 };
@@ -108,6 +129,101 @@ template <int SGN, typename T>
 struct SmallDft<1, SGN, T> {
     static BFSM_HD void run(cx<T>*) {}
 };
+// 3 points: 12 operations (t = b + c; y0 = a + t; m = a - t/2; y1,2 = m +- (+-i) (sqrt(3)/2) (b - c))
+template <int SGN, typename T>
+struct SmallDft<3, SGN, T> {
+    static BFSM_HD void run(cx<T>* a) {
+        constexpr T K = (T)(SGN * 0.86602540378443864676);   // sin(2 pi / 3), signed: w = exp(SGN i 2 pi / 3)
+        const cx<T> t = cadd(a[1], a[2]), d = csub(a[1], a[2]);
+        const cx<T> m = {fmad((T)-0.5, t.x, a[0].x), fmad((T)-0.5, t.y, a[0].y)};
+        a[0] = cadd(a[0], t);
+        a[1] = {fmad(-K, d.y, m.x), fmad(K, d.x, m.y)};      // m + i K d
+        a[2] = {fmad(K, d.y, m.x), fmad(-K, d.x, m.y)};      // m - i K d
+    }
+};
+// Sizes N1 * N2 with coprime factors by the prime-factor (Good-Thomas) index maps: no twiddles between the two
+// stages, only compile-time permutations of registers.
+//   in:  n = (N2 n1 + N1 n2) mod N        out: k = (N2 (N2^-1 mod N1) k1 + N1 (N1^-1 mod N2) k2) mod N
+constexpr int inv_mod(int a, int m) {
+    for (int x = 1; x < m; ++x) if ((a * x) % m == 1) return x;
+    return 1;
+}
+template <int N1, int N2, int SGN, typename T>
+struct SmallDftPfa {
+    static BFSM_HD void run(cx<T>* a) {
+        constexpr int N = N1 * N2, C1 = N2 * inv_mod(N2 % N1, N1), C2 = N1 * inv_mod(N1 % N2, N2);
+        cx<T> t[N2][N1];
+#pragma unroll
+        for (int n2 = 0; n2 < N2; ++n2) {
+#pragma unroll
+            for (int n1 = 0; n1 < N1; ++n1) t[n2][n1] = a[(N2 * n1 + N1 * n2) % N];
+            SmallDft<N1, SGN, T>::run(t[n2]);
+        }
+#pragma unroll
+        for (int k1 = 0; k1 < N1; ++k1) {
+            cx<T> c[N2];
+#pragma unroll
+            for (int n2 = 0; n2 < N2; ++n2) c[n2] = t[n2][k1];
+            SmallDft<N2, SGN, T>::run(c);
+#pragma unroll
+            for (int k2 = 0; k2 < N2; ++k2) a[(C1 * k1 + C2 * k2) % N] = c[k2];
+        }
+    }
+};
+template <int SGN, typename T> struct SmallDft<6, SGN, T> { static BFSM_HD void run(cx<T>* a) { SmallDftPfa<2, 3, SGN, T>::run(a); } };
+template <int SGN, typename T> struct SmallDft<12, SGN, T> { static BFSM_HD void run(cx<T>* a) { SmallDftPfa<4, 3, SGN, T>::run(a); } };
+template <int SGN, typename T> struct SmallDft<24, SGN, T> { static BFSM_HD void run(cx<T>* a) { SmallDftPfa<8, 3, SGN, T>::run(a); } };
+
+// The same DFT of R points whose INPUTS carry twiddle factors: x[j] is to be multiplied by w[j] first (w[0] = 1 when
+// FIRST_ONE).  w holds forward-table values exp(-i...); the backward transform (SGN = +1) uses their conjugates.  The
+// factors are folded into the leaf butterflies of the decimation-in-time tree: x_i w_i +- x_j w_j costs 6 operations
+// when w_i = 1 and 4 + 6 otherwise, against 4 + 4 + 4 for multiply-then-butterfly (8 points: 36 instead of 44).
+template <int R, int SGN, typename T, bool FIRST_ONE>
+struct SmallDftTw {
+    static BFSM_HD void run(cx<T>* a, const cx<T>* w) {
+        static_assert(R == 4 || R == 8 || R == 16, "radix");
+#ifdef BFSM_KO_DFT
+        return;
+#endif
+        cx<T> e[R / 2], o[R / 2], we[R / 2], wo[R / 2];
+#pragma unroll
+        for (int k = 0; k < R / 2; ++k) {
+            e[k] = a[2 * k];
+            o[k] = a[2 * k + 1];
+            we[k] = w[2 * k];
+            wo[k] = w[2 * k + 1];
+        }
+        SmallDftTw<R / 2, SGN, T, FIRST_ONE>::run(e, we);
+        SmallDftTw<R / 2, SGN, T, false>::run(o, wo);
+#pragma unroll
+        for (int k = 0; k < R / 2; ++k) {
+            const int j = k * (16 / R);
+            if (j == 0) {
+                a[k] = cadd(e[k], o[k]);
+                a[k + R / 2] = csub(e[k], o[k]);
+            } else if (j == 4) {
+                const cx<T> t = rot90<SGN>(o[k]);
+                a[k] = cadd(e[k], t);
+                a[k + R / 2] = csub(e[k], t);
+            } else {
+                cx<T> x = e[k], y = o[k];
+                bfly_tw(x, y, (T)cos16(j), (T)(SGN * sin16(j)));
+                a[k] = x;
+                a[k + R / 2] = y;
+            }
+        }
+    }
+};
+template <int SGN, typename T, bool FIRST_ONE>
+struct SmallDftTw<2, SGN, T, FIRST_ONE> {
+    static BFSM_HD void run(cx<T>* a, const cx<T>* w) {
+        cx<T> x = a[0], y = a[1];
+        if (!FIRST_ONE) x = (SGN < 0) ? cmul(x, w[0]) : cmulc(x, w[0]);
+        bfly_tw(x, y, w[1].x, (SGN < 0) ? w[1].y : -w[1].y);
+        a[0] = x;
+        a[1] = y;
+    }
+};
 
 // Compile-time geometry of an N-point line: E points per thread, T threads per line.
 template <int N> struct Geo;
@@ -115,6 +231,12 @@ template <> struct Geo<16>  { static constexpr int E = 4,  T = 4; };
 template <> struct Geo<32>  { static constexpr int E = 8,  T = 4; };
 template <> struct Geo<64>  { static constexpr int E = 8,  T = 8; };
 template <> struct Geo<128> { static constexpr int E = 16, T = 8; };
+// sizes with a factor 3: N = Q T^2 needs T = 4 (the radix-E step is a prime-factor 4 x 3 / 8 x 3 transform)
+template <> struct Geo<48>  { static constexpr int E = 12, T = 4; };
+template <> struct Geo<96>  { static constexpr int E = 24, T = 4; };
+
+// columns per workgroup of the line (x-axis) kernels: a row of N, or a divisor of it that keeps runs >= 384 bytes
+constexpr int line_npl(int n) { return n <= 64 ? n : (n % 64 == 0 ? 64 : n / 2); }
 
 template <int N>
 struct Wg {
@@ -127,7 +249,7 @@ struct Wg {
     // Line kernels (1-D passes along x) only need a set of independent columns, not a whole tile: they take NPL
     // columns per workgroup.  At N = 128 that is half a row, which halves the exchange buffer (66 KiB in fp32) and
     // lets two workgroups share a CU; the 2-D tile kernels keep N columns.
-    static constexpr int NPL = N > 64 ? 64 : N;
+    static constexpr int NPL = line_npl(N);
     static constexpr int LINE_THREADS = NPL * T;
     // N rows for the exchanges; N + 2 so that the Hermitian line kernel can stage the stored halves (N/2 + 1 rows) of
     // both arrays side by side
@@ -148,15 +270,25 @@ constexpr size_t line_lds_bytes() { return (size_t)Wg<N>::LINE_LDS_ELEMS * sizeo
 // ---- one distributed 1-D transform -------------------------------------------------------------------------
 // v[m] = x[u + T*m] on entry, X[u + T*m] on exit.  lds rows are indexed by position along the line, columns
 // by the lane index p.  tw[n] = exp(-2*pi*i*n/N) (forward table; conjugated for SGN = +1).
-// Twiddles<N,T>: this thread's E-1 inter-step twiddles tw[u*k1].  Normally they are loaded once per kernel
-// (wave-uniform for N >= 64, so they live in SGPRs and cost no vector-memory latency inside the direction loops);
-// in the split-exchange geometry (N = 128, fp64: 60 SGPRs of twiddles next to 64 of phase factors would spill) only
-// the table position is kept and every use is a fresh scalar load from the constant cache.
+//
+//   X[k1 + E k2] = sum_u W_T^(u k2) * W_N^(u k1) * ( sum_m x[u + T m] W_E^(m k1) )
+//
+// Step 1: every thread transforms its E points (radix E).  Exchange: thread u' receives, for its Q values
+// k1 = u' + T q, the results of all T threads of the line.  Step 2: radix-T transforms over the source thread uu whose
+// inputs carry the inter-step twiddles W_N^(uu k1); they are folded into the leaf butterflies (SmallDftTw), which is
+// cheaper than multiplying before the exchange and lets the LDS stores issue straight after step 1.
+// Twiddles<N,T>: this thread's (T-1) Q inter-step twiddles tw[uu * (u + T q)].  Normally they are loaded once per
+// kernel (wave-uniform for N >= 64, so they live in SGPRs and cost no vector-memory latency inside the direction
+// loops); in the split-exchange geometry (N = 128, fp64: SGPRs of twiddles next to those of phase factors would
+// spill) only the table position is kept and every use is a fresh scalar load from the constant cache.
 template <int N, typename T>
 struct Twiddles {
-    static constexpr bool HELD = !split_tile<N, T>();
-    cx<T> w[HELD ? Wg<N>::E - 1 : 1];
-    const cx<T>* row;   // tw + 0, indexed by u*k1
+    // not held either where they would be per-lane data (rows of N lanes that do not cover whole waves) of more than
+    // 16 registers' worth next to E = 24 points per thread (N = 96): re-read through the vector cache at every use
+    static constexpr bool HELD = !split_tile<N, T>() && !(N % 64 != 0 && Wg<N>::E >= 24);
+    static constexpr int TT = Wg<N>::T, Q = Wg<N>::Q;
+    cx<T> w[HELD ? (TT - 1) * Q : 1];
+    const cx<T>* row;   // tw + 0
     int u;
     template <class Ctx>
     BFSM_HD void load(const cx<T>* tw, int u_, Ctx& ctx) {
@@ -164,13 +296,19 @@ struct Twiddles {
         u = u_;
         if constexpr (HELD) {
 #pragma unroll
-            for (int k1 = 1; k1 < Wg<N>::E; ++k1) w[k1 - 1] = ctx.ldc(tw + u_ * k1);
+            for (int q = 0; q < Q; ++q)
+#pragma unroll
+                for (int uu = 1; uu < TT; ++uu) w[q * (TT - 1) + uu - 1] = ctx.ldc(tw + ((uu * (u_ + TT * q)) % N));
         }
     }
+    // twiddle of the value that source thread uu contributes to this thread's q-th sub-transform (uu >= 1)
     template <class Ctx>
-    BFSM_HD cx<T> get(int k1, Ctx& ctx) const {
-        if constexpr (HELD) return w[k1 - 1];
-        else return ctx.ldc(row + ctx.opaque(u) * k1);   // opaque: keeps the load where it is used (no hoisting)
+    BFSM_HD cx<T> get(int q, int uu, Ctx& ctx) const {
+        if constexpr (HELD) return w[q * (TT - 1) + uu - 1];
+        else {                                    // opaque: keeps the load where it is used (no hoisting out of the loops)
+            const int uo = (N % 64 == 0) ? ctx.opaque(u) : ctx.opaque_v(u);
+            return ctx.ldc(row + ((uu * (uo + TT * q)) % N));
+        }
     }
 };
 
@@ -190,16 +328,30 @@ enum : int { SYNC_PRE = 1, SYNC_POST = 2 };
 #define BFSM_SYNC_FIX(x) (x)
 #endif
 
+// step 2 of a line transform on the exchanged values w2[q*T + uu]; result back in v (distribution u + T*m)
+template <int N, int SGN, typename T, class Ctx>
+BFSM_HD void fft_line_step2(cx<T>* v, cx<T>* w2, const Twiddles<N, T>& twr, Ctx& ctx) {
+    constexpr int TT = Wg<N>::T, Q = Wg<N>::Q;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        cx<T> w[TT];
+        w[0] = {(T)1, (T)0};
+#pragma unroll
+        for (int uu = 1; uu < TT; ++uu) w[uu] = twr.get(q, uu, ctx);
+        SmallDftTw<TT, SGN, T, true>::run(w2 + q * TT, w);
+    }
+    // output index k1 + E*k2 with k1 = u + T*q  ==  u + T*(q + Q*k2)
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int k2 = 0; k2 < TT; ++k2) v[q + Q * k2] = w2[q * TT + k2];
+}
+
 template <int N, int NP, int SGN, typename T, bool SPLIT = false, int SYNC_ = SYNC_PRE, class Ctx>
 BFSM_HD void fft_line_np(cx<T>* v, cx<T>* lds, int p, int u, const Twiddles<N, T>& twr, Ctx& ctx) {
     constexpr int E = Wg<N>::E, TT = Wg<N>::T, Q = Wg<N>::Q, LS = NP + 1;   // p in [0, NP): LDS column
     constexpr int SYNC = BFSM_SYNC_FIX(SYNC_);
     SmallDft<E, SGN, T>::run(v);
-#pragma unroll
-    for (int k1 = 1; k1 < E; ++k1) {
-        const cx<T> w = twr.get(k1, ctx);
-        v[k1] = (SGN < 0) ? cmul(v[k1], w) : cmulc(v[k1], w);
-    }
     cx<T> w2[E];
     if constexpr (!SPLIT) {
         if constexpr ((SYNC & SYNC_PRE) != 0) ctx.sync();
@@ -231,18 +383,12 @@ BFSM_HD void fft_line_np(cx<T>* v, cx<T>* lds, int p, int u, const Twiddles<N, T
             for (int uu = 0; uu < TT; ++uu) w2[q * TT + uu].y = ctx.lds_ld_s(ls + ((u + TT * q) * TT + uu) * LS + p);
         if constexpr ((SYNC & SYNC_POST) != 0) ctx.sync();
     }
-#pragma unroll
-    for (int q = 0; q < Q; ++q) SmallDft<TT, SGN, T>::run(w2 + q * TT);
-    // output index k1 + E*k2 with k1 = u + T*q  ==  u + T*(q + Q*k2)
-#pragma unroll
-    for (int q = 0; q < Q; ++q)
-#pragma unroll
-        for (int k2 = 0; k2 < TT; ++k2) v[q + Q * k2] = w2[q * TT + k2];
+    fft_line_step2<N, SGN, T>(v, w2, twr, ctx);
 }
 
-template <int N, int SGN, typename T, int SYNC_ = SYNC_PRE, class Ctx>
+template <int N, int SGN, typename T, int SYNC_ = SYNC_PRE, bool SPLIT = split_tile<N, T>(), class Ctx>
 BFSM_HD void fft_line(cx<T>* v, cx<T>* lds, int p, int u, const Twiddles<N, T>& twr, Ctx& ctx) {
-    fft_line_np<N, N, SGN, T, split_tile<N, T>(), SYNC_>(v, lds, p, u, twr, ctx);
+    fft_line_np<N, N, SGN, T, SPLIT, SYNC_>(v, lds, p, u, twr, ctx);
 }
 
 // ---- 2-D transform of an N x N tile with transposition -------------------------------------------------------
@@ -250,14 +396,16 @@ BFSM_HD void fft_line(cx<T>* v, cx<T>* lds, int p, int u, const Twiddles<N, T>& 
 // exit : v[m] = TILE[a' = p][c' = u + T*m]    (to be stored as out[c'][a'], a' contiguous)
 // LAST_POST: close the last exchange with a barrier behind its reads (pays when arithmetic or stores follow: KA) or leave
 // it open for the next tile's first exchange (pays when the next tile's global loads follow: KC at two workgroups per CU).
-template <int N, int SGN, typename T, bool LAST_POST = false, class Ctx>
+// SPLIT: exchange the real and the imaginary parts one after the other through a buffer of scalars (forced where the
+// complex tile does not fit the LDS; chosen for KC at N = 96 in double precision, see kc_split).
+template <int N, int SGN, typename T, bool LAST_POST = false, bool SPLIT = split_tile<N, T>(), class Ctx>
 BFSM_HD void fft_tile(cx<T>* v, cx<T>* lds, int p, int u, const Twiddles<N, T>& twr, Ctx& ctx) {
     constexpr int E = Wg<N>::E, TT = Wg<N>::T, LS = Wg<N>::LS;
     // the split-exchange geometry keeps the round-1 placement (measured: the new one is slower there)
-    constexpr bool OLD = split_tile<N, T>();
+    constexpr bool OLD = SPLIT;
     constexpr int SYNC = OLD ? SYNC_PRE : BFSM_SYNC_FIX(SYNC_POST);   // the transposing exchange
-    fft_line<N, SGN, T, OLD ? SYNC_PRE : (SYNC_PRE | SYNC_POST)>(v, lds, p, u, twr, ctx);  // along a
-    if constexpr (!split_tile<N, T>()) {
+    fft_line<N, SGN, T, OLD ? SYNC_PRE : (SYNC_PRE | SYNC_POST), SPLIT>(v, lds, p, u, twr, ctx);  // along a
+    if constexpr (!SPLIT) {
         if constexpr ((SYNC & SYNC_PRE) != 0) ctx.sync();
 #pragma unroll
         for (int m = 0; m < E; ++m) ctx.lds_st(lds + (u + TT * m) * LS + p, v[m]);  // row a', column c
@@ -281,8 +429,15 @@ BFSM_HD void fft_tile(cx<T>* v, cx<T>* lds, int p, int u, const Twiddles<N, T>& 
         for (int m = 0; m < E; ++m) v[m].y = ctx.lds_ld_s(ls + p * LS + (u + TT * m));
         if constexpr ((SYNC & SYNC_POST) != 0) ctx.sync();
     }
-    fft_line<N, SGN, T, OLD ? SYNC_PRE : (LAST_POST ? SYNC_POST : 0)>(v, lds, p, u, twr, ctx);  // along c
+    fft_line<N, SGN, T, OLD ? SYNC_PRE : (LAST_POST ? SYNC_POST : 0), SPLIT>(v, lds, p, u, twr, ctx);  // along c
 }
+
+// KC streams a whole segment before its one transform, so what it needs from the CU is waves in flight, not exchange
+// speed.  Where the complex tile admits a single 6-wave workgroup per CU (N = 96, fp64: 149 KiB) it exchanges the real
+// and imaginary parts separately through 75 KiB instead, so that two workgroups share a CU.
+template <int N, typename T> constexpr bool kc_split() { return split_tile<N, T>() || (N == 96 && sizeof(T) == 8); }
+template <int N, typename T>
+constexpr size_t kc_lds_bytes() { return (size_t)Wg<N>::LDS_ELEMS * (kc_split<N, T>() ? sizeof(T) : sizeof(cx<T>)); }
 
 // ------------------------------------------------------------------------------------------------------------
 // Kernel parameter blocks (plain pointers and sizes; filled by the host pipeline)
@@ -500,6 +655,21 @@ BFSM_HD void body_line(const LineParams<T>& prm, Ctx& ctx) {
     for (int m = 0; m < E; ++m) prm.out[base + (size_t)(u + TT * m) * N * N] = v[m];
 }
 
+// KA keeps its f_hat plane in registers across the direction loop unless that is more than 64 registers per thread next
+// to two tiles' worth of transform data (the split-exchange geometry, and E = 24 points per thread in double precision).
+template <int N, typename T> constexpr bool keep_plane() { return !split_tile<N, T>() && Wg<N>::E * sizeof(cx<T>) <= 256; }
+
+// KA processes the two signs of a direction as a software-pipelined pair of tiles where the geometry leaves one
+// workgroup per CU and the exchange buffer holds complex elements (N = 128 in single precision).
+// BFSM_NO_PIPELINED_PAIR restores the one-tile-after-the-other form (A/B measurements).
+template <int N, typename T> constexpr bool pipelined_pair() {
+#ifdef BFSM_NO_PIPELINED_PAIR
+    return false;
+#else
+    return N >= 128 && !split_tile<N, T>();
+#endif
+}
+
 // KA.  grid = (N planes lx, groups).  For each direction of the group and both signs: phase multiply
 // (compute_alpha_times_f_hat, BoltzmannCUDAKernels.cu:21-59, with the sincos hoisted into separable tables)
 // fused with the (lz,ly) -> (y,z) part of the two batched inverse transforms (CUDABoltzmannOperator.cu:156-164).
@@ -514,7 +684,7 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
     // The workgroup's f_hat plane stays in registers across the direction loop, except in the one geometry whose
     // 1024-thread workgroup leaves 128 VGPRs for 2 x 64 of data (N = 128, fp64): there it is re-read every
     // iteration (a 256 KiB plane shared by the workgroups of the plane: L2 / Infinity Cache traffic).
-    constexpr bool KEEP = !split_tile<N, T>();
+    constexpr bool KEEP = keep_plane<N, T>();
     cx<T> fh[KEEP ? E : 1];
     const size_t bz = (size_t)ctx.bz();
     const cx<T>* src = prm.fhat + bz * N * N * N + (size_t)lxi * N * N;
@@ -525,7 +695,116 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
     const int d_begin = ctx.by() * prm.per_group;
     int d_end = d_begin + prm.per_group;
     if (d_end > prm.n_dir) d_end = prm.n_dir;
-    if constexpr (N >= 64 && KEEP) {
+    if constexpr (pipelined_pair<N, T>()) {
+        // N = 128 (one 1024-thread workgroup per CU: no second workgroup to overlap with).  The two signs of a direction
+        // are two independent tiles A (alpha) and B (conj alpha); they go through the workgroup's ONE exchange buffer
+        // alternately, B one stage behind A, so that every burst of LDS stores drains under the other tile's butterflies
+        // instead of in front of a barrier:
+        //    dft(A) | wr A, dft(B) | rd A | wr B, step2(A) | rd B | wr^T A, step2(B) | rd^T A | wr^T B, dft(A) | rd^T B |
+        //    wr A, dft(B) | rd A | wr B, step2(A), store A | rd B | step2(B), store B
+        // ("|" = barrier; 12 per direction instead of 14).  The phase factors are formed once per point and used for both
+        // signs (the two tiles are live together here anyway).  Measured against the sequential form: see DESIGN.md 7.1.
+        constexpr int Q = Wg<N>::Q, LS = Wg<N>::LS;
+        auto xw_line = [&](const cx<T>* v) {
+#pragma unroll
+            for (int k1 = 0; k1 < E; ++k1) ctx.lds_st(lds + (k1 * TT + u) * LS + p, v[k1]);
+        };
+        auto xr_line = [&](cx<T>* w2) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+#pragma unroll
+                for (int uu = 0; uu < TT; ++uu) w2[q * TT + uu] = ctx.lds_ld(lds + ((u + TT * q) * TT + uu) * LS + p);
+        };
+        auto xw_tr = [&](const cx<T>* v) {
+#pragma unroll
+            for (int m = 0; m < E; ++m) ctx.lds_st(lds + (u + TT * m) * LS + p, v[m]);
+        };
+        auto xr_tr = [&](cx<T>* v) {
+#pragma unroll
+            for (int m = 0; m < E; ++m) v[m] = ctx.lds_ld(lds + p * LS + (u + TT * m));
+        };
+        // last step of a tile: the rows of every radix-T sub-transform are stored as soon as it is done, so the stores of
+        // the first sub-transform(s) leave under the arithmetic of the following one instead of in one burst of E
+        auto step2_store = [&](cx<T>* base, int d, cx<T>* w2) {
+            cx<T>* dst = base + bz * prm.a_bstride + ((size_t)d * prm.planes + lxi) * N * N;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                cx<T> w[TT];
+                w[0] = {(T)1, (T)0};
+#pragma unroll
+                for (int uu = 1; uu < TT; ++uu) w[uu] = twr.get(q, uu, ctx);
+                SmallDftTw<TT, +1, T, true>::run(w2 + q * TT, w);
+#pragma unroll
+                for (int k2 = 0; k2 < TT; ++k2)   // row y = u + T (q + Q k2), z = p
+                    ctx.template st_stream_at<N % 64 == 0>(dst + (size_t)(u + TT * (q + Q * k2)) * N, (unsigned)p * (unsigned)sizeof(cx<T>), w2[q * TT + k2]);
+#ifndef BFSM_KA_STORE_BURST
+                ctx.sched_fence();
+#endif
+            }
+        };
+        cx<T> py = {(T)0, (T)0};
+        if (d_begin < d_end) py = prm.phy[(size_t)(prm.dir0 + d_begin) * N + p];
+        for (int d = d_begin; d < d_end; ++d) {
+            const size_t b = (size_t)(prm.dir0 + d);
+            const cx<T> c0 = cmul(ctx.ldc(prm.phx + b * N + lxi), py);
+            if (d + 1 < d_end) py = prm.phy[(size_t)(prm.dir0 + d + 1) * N + p];
+            T warm = (T)0;     // L2 warm-up of the phase-table rows two directions ahead (see the sequential form below)
+            constexpr int EPL = 64 / (int)sizeof(cx<T>), LINES = N / EPL;
+            const bool warming = (N % 64 == 0) && 2 * LINES <= 64 && prm.warm_tables != 0 && u == 0 && d + 2 < d_end;
+            if (warming) {
+                const size_t bw = (size_t)(prm.dir0 + d + 2);
+                const int l = tid % 64;
+                const cx<T>* row = (l < LINES) ? prm.phz : prm.phy;
+                warm = row[bw * N + (size_t)(l % LINES) * EPL].x;
+            }
+            cx<T> va[E], vb[E], wa[E], wb[E];
+#ifdef BFSM_KA_SHARE_PHASE
+            constexpr bool SHARE = true;        // phase factors formed once for both signs: 64 operations fewer, 32 more
+#else                                           // live registers at the first transform (spills at 128 VGPRs: slower)
+            constexpr bool SHARE = false;
+#endif
+#pragma unroll
+            for (int m = 0; m < E; ++m) {
+                const cx<T> ph = cmul(c0, ctx.ldc(prm.phz + b * N + u + TT * m));
+                va[m] = cmul(fh[m], ph);        // alpha1 f_hat / G
+                if constexpr (SHARE) vb[m] = cmulc(fh[m], ph);       // conj(alpha1) f_hat / G
+            }
+            SmallDft<E, +1, T>::run(va);
+            ctx.sync();                         // the previous direction's last exchange has been read
+            xw_line(va);
+            ctx.sched_fence();
+            if constexpr (!SHARE) {
+                const cx<T> c0s = ctx.opaque_cx(c0);
+#pragma unroll
+                for (int m = 0; m < E; ++m) vb[m] = cmulc(fh[m], cmul(c0s, ctx.ldc(prm.phz + b * N + u + TT * m)));
+            }
+            SmallDft<E, +1, T>::run(vb);
+            ctx.sync(); xr_line(wa); ctx.sync();
+            xw_line(vb);
+            ctx.sched_fence();
+            fft_line_step2<N, +1, T>(va, wa, twr, ctx);
+            ctx.sync(); xr_line(wb); ctx.sync();
+            xw_tr(va);
+            ctx.sched_fence();
+            fft_line_step2<N, +1, T>(vb, wb, twr, ctx);
+            ctx.sync(); xr_tr(va); ctx.sync();
+            xw_tr(vb);
+            ctx.sched_fence();
+            SmallDft<E, +1, T>::run(va);
+            ctx.sync(); xr_tr(vb); ctx.sync();
+            xw_line(va);
+            ctx.sched_fence();
+            SmallDft<E, +1, T>::run(vb);
+            ctx.sync(); xr_line(wa); ctx.sync();
+            xw_line(vb);
+            ctx.sched_fence();
+            step2_store(prm.a1, d, wa);
+            ctx.sync(); xr_line(wb);
+            ctx.sched_fence();
+            step2_store(prm.a2, d, wb);
+            if (warming) ctx.keep_alive(warm);
+        }
+    } else if constexpr (N >= 64 && KEEP) {
         // One iteration = one direction; both signs are produced by the same code with the sign a compile-time flag
         // (e^{+-i theta} / G = (phx[lx] * phy[ly = p]) * phz[lz = u + T m], conjugated for sign 1), so no per-point select
         // is executed.  The phz / phx factors are wave-uniform scalar loads; the per-lane phy factor of the NEXT direction
@@ -955,7 +1234,7 @@ BFSM_HD void body_gain_fwd(const GainFwdParams<T>& prm, Ctx& ctx) {
     for (int m = 0; m < E; ++m) acc[m] = {(T)0, (T)0};
     const Segment seg = prm.segs[prm.seg0 + ctx.by()];
 #ifdef BFSM_KC_PER_DIRECTION
-    constexpr bool PER_DIRECTION = !split_tile<N, T>();
+    constexpr bool PER_DIRECTION = !kc_split<N, T>();
 #else
     constexpr bool PER_DIRECTION = false;
 #endif
@@ -985,7 +1264,7 @@ BFSM_HD void body_gain_fwd(const GainFwdParams<T>& prm, Ctx& ctx) {
                 acc[m].y += w * t.y;
             }
         }
-        fft_tile<N, -1, T>(acc, lds, p, u, twr, ctx);
+        fft_tile<N, -1, T, false, kc_split<N, T>()>(acc, lds, p, u, twr, ctx);
     }
     cx<T>* dst = prm.slab + (size_t)ctx.bz() * prm.slab_bstride + ((size_t)(prm.seg0 + ctx.by()) * N + x) * N * N;
 #pragma unroll

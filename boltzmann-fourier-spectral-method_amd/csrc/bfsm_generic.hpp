@@ -339,8 +339,8 @@ struct GenericPipeline {
             return BFSM_ERR_UNSUPPORTED;
         }
         const long long B = (long long)d.n_gl * d.n_sph;
-        plan = PlanInfo();
-        plan.N = 0;
+        plan = PlanInfo();                // exact_reductions / hermitian / antipodal stay false: this path evaluates every
+        plan.N = 0;                       // direction whatever the flags say (include/bfsm.h documents them as no-ops here)
         plan.Gtot = G;
         plan.precision = d.precision;
         plan.n_gl = d.n_gl; plan.n_sph = d.n_sph; plan.sph_eff = d.n_sph;

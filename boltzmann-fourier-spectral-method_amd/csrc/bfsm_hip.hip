@@ -38,6 +38,11 @@ struct DevCtx {
         asm volatile("" : "+s"(v));
         return v;
     }
+    // the same for a per-lane integer
+    __device__ __forceinline__ int opaque_v(int v) const {
+        asm volatile("" : "+v"(v));
+        return v;
+    }
     // a per-lane value the optimiser may not trace back to its origin (no common-subexpression sharing through it)
     template <class T>
     __device__ __forceinline__ cx<T> opaque_cx(cx<T> v) const {
@@ -57,6 +62,9 @@ struct DevCtx {
     // is never paired; its order relative to the other exchange accesses is the program order anyway.
     template <class T>
     __device__ __forceinline__ cx<T> lds_ld(const cx<T>* p) const {
+#ifdef BFSM_KO_LDS
+        { cx<T> z = {(T)threadIdx.x, (T)1}; asm volatile("" : "+v"(z.x), "+v"(z.y)); return z; }
+#endif
 #ifndef BFSM_LDS_PAIRED
         if constexpr (sizeof(T) == 4) {
             typedef T vec2 __attribute__((ext_vector_type(2)));
@@ -71,7 +79,13 @@ struct DevCtx {
         return *p;
     }
     template <class T>
-    __device__ __forceinline__ void lds_st(cx<T>* p, cx<T> v) const { *p = v; }
+    __device__ __forceinline__ void lds_st(cx<T>* p, cx<T> v) const {
+#ifdef BFSM_KO_LDS      // knock-out builds (tools only): timing experiments, wrong results
+        asm volatile("" ::"v"(v.x), "v"(v.y));
+        return;
+#endif
+        *p = v;
+    }
     // scalar element of the split (real / imaginary) exchange (fp64, N = 128): left to the compiler's pairing, which
     // measured faster than unpaired reads in that path
     template <class T>
@@ -112,6 +126,10 @@ struct DevCtx {
     }
     template <bool UNI, class T>
     __device__ __forceinline__ void st_stream_at(cx<T>* row, unsigned byte_off, cx<T> v) const {
+#ifdef BFSM_KO_STORE
+        asm volatile("" ::"v"(v.x), "v"(v.y));
+        return;
+#endif
         if constexpr (!UNI) { st_stream(reinterpret_cast<cx<T>*>(reinterpret_cast<unsigned char*>(row) + byte_off), v); return; }
         typedef T vec2 __attribute__((ext_vector_type(2)));
         typedef unsigned char __attribute__((address_space(1))) * gptr;
@@ -178,6 +196,7 @@ constexpr int kernel_threads() {
 template <K kind, int N, typename T>
 constexpr size_t kernel_lds_bytes() {
     if (kind == K::GainInv && pair_tile<N>()) return pair_lds_bytes<N, T>();
+    if (kind == K::GainFwd) return kc_lds_bytes<N, T>();
     return kind == K::Reduce ? 0 : (is_line_kind(kind) ? line_lds_bytes<N, T>() : tile_lds_bytes<N, T>());
 }
 
@@ -189,6 +208,7 @@ constexpr int kernel_min_waves() {
     if (N == 64) return sizeof(T) == 4 ? BFSM_F32_N64_WAVES : 4;   // fp32 tiles are 33 KiB: more workgroups fit
     if (N == 32) return 4;                                         // 128-thread workgroups: 8 per CU at <= 128 VGPRs
     if (N == 128 && is_line_kind(kind)) return sizeof(T) == 4 ? 4 : 2;   // fp64: 133 KiB of columns, one workgroup per CU
+    if (N == 96 && kind == K::GainFwd && sizeof(T) == 8) return 3;       // two 6-wave workgroups per CU (kc_split)
     return 1;
 }
 
@@ -326,7 +346,9 @@ struct HipBackend {
         switch (N) {
             case 16: launch_n<kind, 16, T>(gx, gy, gz, prm); break;
             case 32: launch_n<kind, 32, T>(gx, gy, gz, prm); break;
+            case 48: launch_n<kind, 48, T>(gx, gy, gz, prm); break;
             case 64: launch_n<kind, 64, T>(gx, gy, gz, prm); break;
+            case 96: launch_n<kind, 96, T>(gx, gy, gz, prm); break;
             case 128: launch_n<kind, 128, T>(gx, gy, gz, prm); break;
             default: break;
         }

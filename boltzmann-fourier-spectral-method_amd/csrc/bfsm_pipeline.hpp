@@ -61,11 +61,11 @@ inline double sincc_ref(double x) {
     return std::sin(x + eps) / (x + eps);
 }
 
-// Cubic grids of these sizes run on the fused three-kernel pipeline; every other supported grid on the size-generic
-// path of bfsm_generic.hpp.
+// Cubic grids of these sizes (N = Q T^2 with T = 4 or 8 threads per line) run on the fused three-kernel pipeline; every
+// other supported grid on the size-generic path of bfsm_generic.hpp.
 inline bool fused_grid(const bfsm_desc& d) {
     const int N = d.nvx;
-    return d.nvx == d.nvy && d.nvx == d.nvz && (N == 16 || N == 32 || N == 64 || N == 128);
+    return d.nvx == d.nvy && d.nvx == d.nvz && (N == 16 || N == 32 || N == 48 || N == 64 || N == 96 || N == 128);
 }
 
 // An axis length the library has a transform for: even (the reference's mode tables need it,
@@ -166,6 +166,18 @@ inline PlanInfo make_plan(const bfsm_desc& d) {
             if (resident > 0 && resident % p.N == 0) {
                 const int unit = resident / p.N;
                 for (int extra = 0; extra < unit && (runs * cuts) % unit != 0; ++extra) ++cuts;
+            } else if (p.N == 48 || p.N == 96) {
+                // sizes whose row count does not divide the resident set: among cuts .. cuts + 3 take the count that
+                // fills its rounds of resident workgroups best (N = 96: two 6-wave workgroups per CU; N = 48: four / eight)
+                const int res = p.N == 96 ? 512 : (p.precision == BFSM_F64 ? 1024 : 2048);
+                int best = cuts;
+                double best_u = 0;
+                for (int c2 = cuts; c2 <= cuts + 3; ++c2) {
+                    const long long w = (long long)p.N * runs * c2, rounds = (w + res - 1) / res;
+                    const double u = (double)w / (double)(rounds * res);
+                    if (u > best_u + 0.02) { best_u = u; best = c2; }
+                }
+                cuts = best;
             }
             for (int r = r_first; r <= r_last; ++r) {
                 long long a0 = (long long)r * p.sph_eff, a1 = a0 + p.sph_eff;
@@ -387,7 +399,7 @@ struct Pipeline {
     }
 
     double cbytes() const { return (double)sizeof(cx<T>); }
-    int line_blocks() const { const int npl = plan.N > 64 ? 64 : plan.N; return plan.N * (plan.N / npl); }   // Wg<N>::NPL
+    int line_blocks() const { return plan.N * (plan.N / line_npl(plan.N)); }   // Wg<N>::NPL columns per workgroup
 
     // f_hat = FFT(f), then the gain term of this shard into qhat (partial Q_gain_hat, spectral layout).
     // nb distributions f_dev[nb][G] are processed by the same launches (grid.z / grid.y = batch member); all
@@ -439,7 +451,7 @@ struct Pipeline {
                 be->template launch<K::GainLineAcc, T>(line_blocks(), c.n_seg, nb, kb, N);
             } else {
                 NyqRowsParams<T> kn{fhat, rnyq, phx, phy, phz, tw, c.dir0, r_bs};
-                const int npl = N > 64 ? 64 : N, ncol = 2 * (N / 2 - 1);
+                const int npl = line_npl(N), ncol = 2 * (N / 2 - 1);
                 be->mark(BFSM_K_GAIN_INV, 0.0);
                 be->template launch<K::NyqRows, T>((ncol + npl - 1) / npl, 2 * c.n, nb, kn, N);
                 GainLineAccHParams<T> kb{a1, a2, rnyq, pseg, dirw, segs, tw, c.dir0, c.seg0, a_bs, s_bs, r_bs};

@@ -48,6 +48,7 @@ struct EmuCtx {
     void sync();       // workgroup barrier
     void sched_fence() const {}   // compiler scheduling hint on the device; nothing to do on the host
     int opaque(int v) const { return v; }
+    int opaque_v(int v) const { return v; }
     template <class U> U opaque_cx(U v) const { return v; }
     template <class T> void keep_alive(T) const {}
     template <class U> U* uniform_ptr(U* p) const { return p; }
@@ -174,6 +175,7 @@ struct EmuBackend {
         const int threads = pair ? bfsm::pair_threads<N>() : kind == bfsm::K::Reduce ? 256
                             : (bfsm::is_line_kind(kind) ? bfsm::Wg<N>::LINE_THREADS : bfsm::Wg<N>::THREADS);
         smem.assign(pair ? bfsm::pair_lds_bytes<N, T>()
+                         : kind == bfsm::K::GainFwd ? bfsm::kc_lds_bytes<N, T>()
                          : (bfsm::is_line_kind(kind) ? bfsm::line_lds_bytes<N, T>() : bfsm::tile_lds_bytes<N, T>()), 0xCD);
         P copy = prm;
         for (int bz = 0; bz < gz; ++bz)
@@ -225,7 +227,9 @@ struct EmuBackend {
         switch (N) {
             case 16: launch_n<kind, 16, T>(gx, gy, gz, prm); break;
             case 32: launch_n<kind, 32, T>(gx, gy, gz, prm); break;
+            case 48: launch_n<kind, 48, T>(gx, gy, gz, prm); break;
             case 64: launch_n<kind, 64, T>(gx, gy, gz, prm); break;
+            case 96: launch_n<kind, 96, T>(gx, gy, gz, prm); break;
             case 128: launch_n<kind, 128, T>(gx, gy, gz, prm); break;
             default: break;
         }
@@ -356,7 +360,7 @@ int bfsm_emu_finish(const bfsm_desc* d, const double* f, const double* qhat_in, 
 
 // Emulated bfsm_fft3d; data = batch*G interleaved complex doubles (narrowed to float when precision == 32).
 int bfsm_emu_fft3d(int N, int precision, double* data, int batch, int sign) {
-    if (N != 16 && N != 32 && N != 64 && N != 128) return BFSM_ERR_UNSUPPORTED;
+    if (N != 16 && N != 32 && N != 48 && N != 64 && N != 96 && N != 128) return BFSM_ERR_UNSUPPORTED;
     if (precision == BFSM_F64) return emu::fft3d_t<double>(N, data, batch, sign);
     return emu::fft3d_t<float>(N, data, batch, sign);
 }

@@ -803,7 +803,8 @@ def _make_box(bfsm, shape, n_gl, n_sph, precision=64, shard=None, max_chunk=0, g
                                                         ((16, 128, 32), 3, 6, 0), ((20, 36, 50), 3, 12, 7)])
 def test_any_box_matches_oracle(torch_cuda, oracle, shape, n_gl, n_sph, max_chunk):
     """Grid generality of the reference's constructors (CUDABoltzmannOperator.hpp:48-54; plans cu:86-100): non-cubic
-    boxes and sizes with factors 3 and 5 run on the size-generic path and match the oracle at the fp64 tolerance."""
+    boxes and sizes with factors 3 and 5 match the oracle at the fp64 tolerance (the cubes 48^3 and 96^3 on the fused
+    pipeline's radix-3 geometries, everything else on the size-generic path)."""
     import bfsm
     torch = torch_cuda
     c = bfsm.reference_constants()
@@ -1060,3 +1061,58 @@ def test_batch_of_one_equals_a_single_evaluation_bitwise(torch_cuda):
         op.computeCollisionBatch(Qb, f, 1)
         assert np.array_equal(Q1.cpu().numpy(), Qb.cpu().numpy())
         op.destroy()
+
+
+@pytest.mark.parametrize("mode", ["faithful", "exact", "hermitian"])
+@pytest.mark.parametrize("nv,n_gl,n_sph,prec", [(48, 4, 12, 64), (96, 2, 12, 64), (48, 4, 12, 32), (96, 2, 12, 32)])
+def test_fused_radix3_sizes_match_oracle(torch_cuda, oracle, nv, n_gl, n_sph, prec, mode):
+    """N = 48 and N = 96 on the fused three-kernel pipeline (12 / 24 points per thread, prime-factor 4 x 3 / 8 x 3
+    register transforms, 4 threads per line): whole field on the perturbed input against the oracle, all three modes,
+    both precisions; plus a direction shard pair and a batch member."""
+    import bfsm
+    torch = torch_cuda
+    f_h, ref = _full_ref(oracle, nv, n_gl, n_sph)
+    tol = TOL64 if prec == 64 else TOL32
+    op = _make(bfsm, nv, n_gl, n_sph, prec, exact=(mode != "faithful"), hermitian=(mode == "hermitian"))
+    assert op.counters().exact_reductions == (0 if mode == "faithful" else 1)      # the fused pipeline, not the generic path
+    got = _collide(torch, op, f_h)
+    op.destroy()
+    assert np.abs(got - ref).max() <= tol * np.abs(ref).max()
+    if mode == "faithful" and prec == 64:
+        B = n_gl * n_sph
+        f = torch.from_numpy(f_h).cuda()
+        parts = []
+        for r in range(2):
+            op = _make(bfsm, nv, n_gl, n_sph, prec, shard=bfsm.shard_range(B, r, 2))
+            Q = torch.empty_like(f)
+            op.collidePartial(Q, f, r == 0)
+            torch.cuda.synchronize()
+            parts.append(Q.cpu().numpy())
+            op.destroy()
+        assert np.abs(parts[0] + parts[1] - ref).max() <= tol * np.abs(ref).max()
+
+
+def test_size_generic_path_accepts_and_ignores_the_reduction_flags(torch_cuda, oracle):
+    """include/bfsm.h: on boxes served by the size-generic path BFSM_FLAG_EXACT_REDUCTIONS / BFSM_FLAG_HERMITIAN are
+    accepted and have no effect: same result bit for bit, and the counters report exact_reductions = 0."""
+    import bfsm
+    torch = torch_cuda
+    c = bfsm.reference_constants()
+    shape, n_gl, n_sph = (16, 24, 8), 2, 12
+    f_h = np.random.default_rng(3).random(shape) + 0.1
+    f = torch.from_numpy(f_h).cuda()
+    res = []
+    for exact, herm in ((False, False), (True, False), (True, True)):
+        op = bfsm.HIPBoltzmannOperator(bfsm.GaussLegendreQuadrature(n_gl, 0.0, c["R"]), bfsm.SphericalDesign(n_sph),
+                                       shape[0], shape[1], shape[2], 0.0, 1.0 / (4.0 * np.pi), 11.0)
+        op.setExactReductions(exact, hermitian=herm)
+        op.initialize()
+        cn = op.counters()
+        assert cn.exact_reductions == 0 and cn.antipodal_merged == 0
+        Q = torch.empty_like(f)
+        op(Q, f)
+        res.append(Q.cpu().numpy())
+        op.destroy()
+    assert np.array_equal(res[0], res[1]) and np.array_equal(res[0], res[2])
+    ref = oracle.collide(f_h, oracle.gauss_legendre(n_gl, 0.0, c["R"]), oracle.spherical_design(n_sph), 0.0, 1.0 / (4.0 * np.pi), 11.0)
+    assert np.abs(res[0] - ref).max() <= TOL64 * np.abs(ref).max()
