@@ -396,8 +396,8 @@ BFSM_HD void fft_line(cx<T>* v, cx<T>* lds, int p, int u, const Twiddles<N, T>& 
 // exit : v[m] = TILE[a' = p][c' = u + T*m]    (to be stored as out[c'][a'], a' contiguous)
 // LAST_POST: close the last exchange with a barrier behind its reads (pays when arithmetic or stores follow: KA) or leave
 // it open for the next tile's first exchange (pays when the next tile's global loads follow: KC at two workgroups per CU).
-// SPLIT: exchange the real and the imaginary parts one after the other through a buffer of scalars (forced where the
-// complex tile does not fit the LDS; chosen for KC at N = 96 in double precision, see kc_split).
+// SPLIT: exchange the real and the imaginary parts one after the other through a buffer of scalars (where the complex
+// tile does not fit the LDS).
 template <int N, int SGN, typename T, bool LAST_POST = false, bool SPLIT = split_tile<N, T>(), class Ctx>
 BFSM_HD void fft_tile(cx<T>* v, cx<T>* lds, int p, int u, const Twiddles<N, T>& twr, Ctx& ctx) {
     constexpr int E = Wg<N>::E, TT = Wg<N>::T, LS = Wg<N>::LS;
@@ -432,10 +432,10 @@ BFSM_HD void fft_tile(cx<T>* v, cx<T>* lds, int p, int u, const Twiddles<N, T>& 
     fft_line<N, SGN, T, OLD ? SYNC_PRE : (LAST_POST ? SYNC_POST : 0), SPLIT>(v, lds, p, u, twr, ctx);  // along c
 }
 
-// KC streams a whole segment before its one transform, so what it needs from the CU is waves in flight, not exchange
-// speed.  Where the complex tile admits a single 6-wave workgroup per CU (N = 96, fp64: 149 KiB) it exchanges the real
-// and imaginary parts separately through 75 KiB instead, so that two workgroups share a CU.
-template <int N, typename T> constexpr bool kc_split() { return split_tile<N, T>() || (N == 96 && sizeof(T) == 8); }
+// KC's exchange form.  (Measured at N = 96 in double precision, where the complex tile admits one 6-wave workgroup per
+// CU: exchanging the real and imaginary parts separately through 75 KiB so that two workgroups share a CU does not
+// speed up its streaming loop -- 1.70 against 1.65 ms for 384 directions -- so KC keeps the geometry's own form.)
+template <int N, typename T> constexpr bool kc_split() { return split_tile<N, T>(); }
 template <int N, typename T>
 constexpr size_t kc_lds_bytes() { return (size_t)Wg<N>::LDS_ELEMS * (kc_split<N, T>() ? sizeof(T) : sizeof(cx<T>)); }
 
@@ -590,6 +590,25 @@ struct TailLineParams {      // tail step 2: x inverse of both, Q = Re(gain) - R
 };
 
 BFSM_HD int mode_of(int i, int n) { return i < n / 2 ? i : i - n; }
+
+// XCD-aware block index.  Workgroups are handed to the 8 XCDs round-robin by their linear id, and every XCD has its own
+// L2.  Where the workgroups of one grid row (same by) re-read the same small table, the (bx, by) pair is re-derived so
+// that the workgroups an XCD receives form a contiguous run of the linear order, i.e. whole rows: the table is then
+// fetched into one L2 instead of eight.  A bijection of the grid (when its size is a multiple of 8; identity otherwise);
+// placement is a speed matter only, any mapping is correct.
+template <class Ctx>
+BFSM_HD void xcd_rows(Ctx& ctx, int& bx, int& by) {
+    const int gx = ctx.gx(), w = gx * ctx.gy();
+    bx = ctx.bx();
+    by = ctx.by();
+#ifndef BFSM_NO_XCD_ROWS
+    if (w % 8 == 0) {
+        const int id = by * gx + bx, id2 = (id % 8) * (w / 8) + id / 8;
+        bx = id2 % gx;
+        by = id2 / gx;
+    }
+#endif
+}
 
 template <bool B> struct BoolTag { static constexpr bool value = B; };
 
@@ -1172,9 +1191,13 @@ BFSM_HD void body_gain_line_acc_h(const GainLineAccHParams<T>& prm, Ctx& ctx) {
     cx<T>* lds = ctx.template lds<cx<T>>();
     Twiddles<N, T> twr;
     twr.load(prm.tw, u, ctx);
-    const Segment seg = prm.segs[prm.seg0 + ctx.by()];
+    // the workgroups of a segment share the Nyquist rows R of its directions (31 KiB per direction and array at N = 64):
+    // keep them on one XCD (measured: 1.20 x -> 1.0x of the stored bytes fetched)
+    int gbx, gby;
+    xcd_rows(ctx, gbx, gby);
+    const Segment seg = prm.segs[prm.seg0 + gby];
     constexpr int BPR = N / NPL;                               // column blocks per row of N
-    const int y = ctx.bx() / BPR, z0 = (ctx.bx() % BPR) * NPL;   // y, z0 are uniform over the workgroup; z = z0 + p
+    const int y = gbx / BPR, z0 = (gbx % BPR) * NPL;           // y, z0 are uniform over the workgroup; z = z0 + p
     const int colrow = y * N + z0;
     const unsigned pl = (unsigned)p * (unsigned)sizeof(cx<T>);
     cx<T> acc[E];
@@ -1207,7 +1230,7 @@ BFSM_HD void body_gain_line_acc_h(const GainLineAccHParams<T>& prm, Ctx& ctx) {
         }
     }
     fft_line_np<N, NPL, -1, T>(acc, lds, p, u, twr, ctx);
-    const size_t obase = (size_t)ctx.bz() * prm.pseg_bstride + (size_t)(prm.seg0 + ctx.by()) * N * N * N + colrow;
+    const size_t obase = (size_t)ctx.bz() * prm.pseg_bstride + (size_t)(prm.seg0 + gby) * N * N * N + colrow;
 #pragma unroll
     for (int m = 0; m < E; ++m)
         ctx.template st_at<NPL % 64 == 0>(prm.pseg + obase + (size_t)(u + TT * m) * N * N, pl, acc[m]);

@@ -26,6 +26,8 @@ struct DevCtx {
     __device__ __forceinline__ int bx() const { return (int)blockIdx.x; }
     __device__ __forceinline__ int by() const { return (int)blockIdx.y; }
     __device__ __forceinline__ int bz() const { return (int)blockIdx.z; }
+    __device__ __forceinline__ int gx() const { return (int)gridDim.x; }
+    __device__ __forceinline__ int gy() const { return (int)gridDim.y; }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
     // nothing is scheduled across this point (bounds how many loads the compiler keeps in flight, i.e. registers)
     __device__ __forceinline__ void sched_fence() const { __builtin_amdgcn_sched_barrier(0); }
@@ -208,7 +210,6 @@ constexpr int kernel_min_waves() {
     if (N == 64) return sizeof(T) == 4 ? BFSM_F32_N64_WAVES : 4;   // fp32 tiles are 33 KiB: more workgroups fit
     if (N == 32) return 4;                                         // 128-thread workgroups: 8 per CU at <= 128 VGPRs
     if (N == 128 && is_line_kind(kind)) return sizeof(T) == 4 ? 4 : 2;   // fp64: 133 KiB of columns, one workgroup per CU
-    if (N == 96 && kind == K::GainFwd && sizeof(T) == 8) return 3;       // two 6-wave workgroups per CU (kc_split)
     return 1;
 }
 

@@ -168,8 +168,8 @@ inline PlanInfo make_plan(const bfsm_desc& d) {
                 for (int extra = 0; extra < unit && (runs * cuts) % unit != 0; ++extra) ++cuts;
             } else if (p.N == 48 || p.N == 96) {
                 // sizes whose row count does not divide the resident set: among cuts .. cuts + 3 take the count that
-                // fills its rounds of resident workgroups best (N = 96: two 6-wave workgroups per CU; N = 48: four / eight)
-                const int res = p.N == 96 ? 512 : (p.precision == BFSM_F64 ? 1024 : 2048);
+                // fills its rounds of resident workgroups best (N = 96: one / two 6-wave workgroups per CU; N = 48: four / eight)
+                const int res = p.N == 96 ? (p.precision == BFSM_F64 ? 256 : 512) : (p.precision == BFSM_F64 ? 1024 : 2048);
                 int best = cuts;
                 double best_u = 0;
                 for (int c2 = cuts; c2 <= cuts + 3; ++c2) {

@@ -24,6 +24,9 @@ struct EmuCtx {
     int tid_, nthreads_, bx_, by_, bz_;
     unsigned char* smem;
     Sched* sched;
+    int gx_ = 1, gy_ = 1;
+    int gx() const { return gx_; }
+    int gy() const { return gy_; }
     int tid() const { return tid_; }
     int nthreads() const { return nthreads_; }
     int bx() const { return bx_; }
@@ -82,14 +85,15 @@ struct Sched {
     }
     void yield(State st) { const int me = current; state[me] = st; swapcontext(&ctxs[me], &main_ctx); }
 
-    void run_block(int nthreads, int bx, int by, int bz, unsigned char* smem, void (*fn)(void*, EmuCtx&), void* a) {
+    void run_block(int nthreads, int bx, int by, int bz, unsigned char* smem, void (*fn)(void*, EmuCtx&), void* a,
+                   int gx = 1, int gy = 1) {
         entry = fn; arg = a;
         if ((int)ctxs.size() < nthreads) { ctxs.resize(nthreads); stacks.resize((size_t)nthreads * STACK); }
         state.assign(nthreads, RUN);
         ectx.resize(nthreads);
         active() = this;
         for (int t = 0; t < nthreads; ++t) {
-            ectx[t] = EmuCtx{t, nthreads, bx, by, bz, smem, this};
+            ectx[t] = EmuCtx{t, nthreads, bx, by, bz, smem, this, gx, gy};
             getcontext(&ctxs[t]);
             ctxs[t].uc_stack.ss_sp = stacks.data() + (size_t)t * STACK;
             ctxs[t].uc_stack.ss_size = STACK;
@@ -181,7 +185,7 @@ struct EmuBackend {
         for (int bz = 0; bz < gz; ++bz)
             for (int by = 0; by < gy; ++by)
                 for (int bx = 0; bx < gx; ++bx) {
-                    sched.run_block(threads, bx, by, bz, smem.data(), &body<kind, N, T, P>, &copy);
+                    sched.run_block(threads, bx, by, bz, smem.data(), &body<kind, N, T, P>, &copy, gx, gy);
                     if (sched.deadlock) failed = true;
                 }
     }
