@@ -1,9 +1,9 @@
 // bfsm_generic.hpp -- size-generic path of the collision operator: any even Nvx, Nvy, Nvz <= 256 whose prime factors
-// are 2, 3, 5 (non-cubic boxes, N = 48, 96, ...), which the reference plans with cufftPlan3d / cufftPlanMany
+// are 2, 3, 5, 7, 11, 13 (non-cubic boxes, N = 24, 80, 112, ...), which the reference plans with cufftPlan3d / cufftPlanMany
 // (Collisions/CUDABoltzmannOperator.cu:86-100) and fftw_plan_dft_3d (Collisions/FFTWBoltzmannOperator.cpp:64-65).
 //
-// The cubic grids N in {16, 32, 64, 128} run on the fused three-kernel pipeline of bfsm_core.hpp (6 array passes per
-// direction); everything else runs here: one batched 1-D mixed-radix Stockham pass per axis, transformed in LDS, with
+// The cubic grids N in {16, 32, 48, 64, 96, 128} run on the fused three-kernel pipeline of bfsm_core.hpp (6 array passes
+// per direction); everything else runs here: one batched 1-D mixed-radix Stockham pass per axis, transformed in LDS, with
 // the pointwise steps of the reference fused into the pass that touches the data first
 //     phase multiply (compute_alpha_times_f_hat, BoltzmannCUDAKernels.cu:21-59)  -> load side of the first inverse pass
 //     hadamard_product (Kernels.cu:62-74)                                        -> load side of the first forward pass
@@ -121,6 +121,28 @@ BFSM_HD void gen_dft(cx<T>* x, int sgn) {
     }
 }
 
+// Odd prime radices without a hand-written butterfly (7, 11, 13): direct R x R transform with the roots of unity read
+// from the axis' own twiddle table (R divides n, so exp(-2 pi i m / R) = tw[m n / R]).  O(R^2) per point group: sizes
+// with these factors are served, not tuned.
+template <int R, typename T>
+BFSM_HD void gen_dft_table(cx<T>* x, int sgn, const cx<T>* tw, int n) {
+    cx<T> y[R];
+    const int step = n / R;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        cx<T> acc = x[0];
+#pragma unroll
+        for (int j = 1; j < R; ++j) {
+            const cx<T> w = tw[((j * k) % R) * step];
+            const cx<T> t = sgn < 0 ? cmul(x[j], w) : cmulc(x[j], w);
+            acc = cadd(acc, t);
+        }
+        y[k] = acc;
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) x[k] = y[k];
+}
+
 // Lines per workgroup and thread geometry of a pass: 256 threads = 16 lines x 16 "rows"; thread (row, line) walks the
 // points row, row + 16, ... of its line, so no per-element integer division is ever needed.
 constexpr int GEN_C = 16;
@@ -147,7 +169,8 @@ BFSM_HD void gen_pass(const cx<T>* src, cx<T>* dst, const cx<T>* tw, int n, int 
                 x[q] = sgn < 0 ? cmul(x[q], w) : cmulc(x[q], w);
             }
         }
-        gen_dft<R, T>(x, sgn);
+        if constexpr (R == 7 || R == 11 || R == 13) gen_dft_table<R, T>(x, sgn, tw, n);
+        else gen_dft<R, T>(x, sgn);
         const int j0 = hi * ns * R + k;
 #pragma unroll
         for (int q = 0; q < R; ++q) dst[(j0 + q * ns) * GEN_LS + col] = x[q];
@@ -234,8 +257,11 @@ BFSM_HD void body_gen_fft(const GenFftParams<T>& prm, Ctx& ctx) {
         else if (R == 2) gen_pass<2, true, T>(src, dst, prm.tw, n, ns, prm.sign, ctx);
         else if (R == 3 && p2) gen_pass<3, true, T>(src, dst, prm.tw, n, ns, prm.sign, ctx);
         else if (R == 3) gen_pass<3, false, T>(src, dst, prm.tw, n, ns, prm.sign, ctx);
-        else if (p2) gen_pass<5, true, T>(src, dst, prm.tw, n, ns, prm.sign, ctx);
-        else gen_pass<5, false, T>(src, dst, prm.tw, n, ns, prm.sign, ctx);
+        else if (R == 5 && p2) gen_pass<5, true, T>(src, dst, prm.tw, n, ns, prm.sign, ctx);
+        else if (R == 5) gen_pass<5, false, T>(src, dst, prm.tw, n, ns, prm.sign, ctx);
+        else if (R == 7) gen_pass<7, false, T>(src, dst, prm.tw, n, ns, prm.sign, ctx);
+        else if (R == 11) gen_pass<11, false, T>(src, dst, prm.tw, n, ns, prm.sign, ctx);
+        else gen_pass<13, false, T>(src, dst, prm.tw, n, ns, prm.sign, ctx);
         ns *= R;
         ctx.sync();
         cx<T>* t = src; src = dst; dst = t;
@@ -283,6 +309,7 @@ inline bool gen_factor(int n, std::vector<int>& radix) {
     while (n % 2 == 0) { radix.push_back(2); n /= 2; }
     while (n % 3 == 0) { radix.push_back(3); n /= 3; }
     while (n % 5 == 0) { radix.push_back(5); n /= 5; }
+    for (int r : {7, 11, 13}) while (n % r == 0) { radix.push_back(r); n /= r; }
     return n == 1 && radix.size() <= 8;
 }
 

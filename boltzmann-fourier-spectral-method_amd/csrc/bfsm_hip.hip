@@ -143,7 +143,11 @@ struct DevCtx {
 #pragma clang diagnostic ignored "-Wold-style-cast"
         gptr g = (gptr)(reinterpret_cast<unsigned char*>(row));
         asm volatile("" : "+s"(g));
+#ifdef BFSM_PLAIN_STORES    // A/B builds (tools only): ordinary stores for the streamed scratch
+        *(gvec)(g + byte_off) = r;
+#else
         __builtin_nontemporal_store(r, (gvec)(g + byte_off));
+#endif
 #pragma clang diagnostic pop
     }
     // cacheable (plain) variants of the row + lane-offset accessors

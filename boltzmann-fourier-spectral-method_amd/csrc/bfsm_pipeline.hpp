@@ -69,16 +69,16 @@ inline bool fused_grid(const bfsm_desc& d) {
 }
 
 // An axis length the library has a transform for: even (the reference's mode tables need it,
-// FFTWBoltzmannOperator.cpp:50-57), 4 <= n <= 256, prime factors 2, 3, 5.
+// FFTWBoltzmannOperator.cpp:50-57), 4 <= n <= 256, prime factors 2, 3, 5, 7, 11, 13.
 inline bool axis_supported(int n) {
     if (n < 4 || n > 256 || n % 2 != 0) return false;
-    for (int p : {2, 3, 5}) while (n % p == 0) n /= p;
+    for (int p : {2, 3, 5, 7, 11, 13}) while (n % p == 0) n /= p;
     return n == 1;
 }
 
 inline int validate_desc(const bfsm_desc& d, std::string& err) {
     if (!axis_supported(d.nvx) || !axis_supported(d.nvy) || !axis_supported(d.nvz)) {
-        err = "every grid extent must be even, in [4, 256], with prime factors 2, 3, 5 only";
+        err = "every grid extent must be even, in [4, 256], with prime factors 2, 3, 5, 7, 11, 13 only";
         return BFSM_ERR_UNSUPPORTED;
     }
     if (d.precision != BFSM_F64 && d.precision != BFSM_F32) { err = "precision must be BFSM_F64 or BFSM_F32"; return BFSM_ERR_INVALID; }

@@ -84,11 +84,11 @@ typedef struct bfsm_plan* bfsm_handle;
  * Quadratures/AbstractSphericalQuadratures.hpp:21-42).  All arrays are HOST pointers, copied during create.
  */
 typedef struct bfsm_desc {
-    int nvx, nvy, nvz;        /* velocity grid: every extent even, in [4, 256], prime factors 2, 3, 5 (the reference
-                                 plans any Nvx x Nvy x Nvz, CUDABoltzmannOperator.cu:86-100).  Cubes of 16, 32, 64,
-                                 128 run on the fused pipeline (6 array passes per direction); every other box on
-                                 the size-generic path (one transform pass per axis, several times slower), both precisions.  Anything
-                                 else: BFSM_ERR_UNSUPPORTED */
+    int nvx, nvy, nvz;        /* velocity grid: every extent even, in [4, 256], prime factors 2, 3, 5, 7, 11, 13 (the
+                                 reference plans any Nvx x Nvy x Nvz, CUDABoltzmannOperator.cu:86-100).  Cubes of 16, 32,
+                                 48, 64, 96, 128 run on the fused pipeline (6 array passes per direction); every other box
+                                 on the size-generic path (one transform pass per axis, several times slower), both
+                                 precisions.  Anything else: BFSM_ERR_UNSUPPORTED */
     int n_gl;                 /* Gauss-Legendre points (radial)          */
     int n_sph;                /* spherical quadrature points             */
     const double* gl_nodes;   /* [n_gl]  rho_r on [0,R]                   */

@@ -50,8 +50,8 @@ def test_descriptor_validation_errors_are_reported(libpath):
     p = one.ctypes.data_as(dp)
     h = ctypes.c_void_p()
     # extents the library has no transform for: odd (the reference's mode tables need even sizes), a prime factor other
-    # than 2, 3, 5, or outside [4, 256] -- BFSM_ERR_UNSUPPORTED only beyond the size-generic path
-    for nx, ny, nz in ((15, 16, 16), (16, 14, 16), (16, 16, 22), (512, 16, 16), (2, 16, 16)):
+    # than 2, 3, 5, 7, 11, 13, or outside [4, 256] -- BFSM_ERR_UNSUPPORTED only beyond the size-generic path
+    for nx, ny, nz in ((15, 16, 16), (16, 34, 16), (16, 16, 38), (512, 16, 16), (2, 16, 16)):
         bad_n = capi.Desc(nx, ny, nz, 4, 4, p, p, p, p, p, p, 0.0, 1.0, 1.0, 64, 0, 0, 0, 0, 0)
         assert L.bfsm_create(ctypes.byref(bad_n), ctypes.byref(h)) == 2 and not h.value
         assert b"grid extent" in L.bfsm_last_error(None)

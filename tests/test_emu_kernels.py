@@ -127,7 +127,7 @@ def test_plan_rejects_unsupported():
     with pytest.raises(ValueError):
         E.plan(50 * 7, 2, 6)                      # 350: beyond 256 and a factor 7
     with pytest.raises(ValueError):
-        E.plan(14, 2, 6)                          # prime factor 7
+        E.plan(34, 2, 6)                          # prime factor 17
     E.plan(128, 2, 6, 64)                # N=128 in fp64 is planned like any other size (split-exchange tiles)
     with pytest.raises(ValueError):
         E.plan(16, 2, 6, 16)             # precision must be 32 or 64
@@ -317,6 +317,8 @@ def test_randomised_plans_against_the_oracle(oracle):
     ((16, 8, 6), 3, 12, 64, 1e-12, {"max_chunk": 5}),        # several chunks of directions
     ((16, 8, 6), 3, 12, 64, 1e-12, {"dir_range": (7, 29)}),  # a direction shard
     ((8, 16, 4), 2, 6, 32, 2e-5, {}),                        # single-precision variant
+    ((14, 22, 26), 2, 6, 64, 1e-12, {}),                     # radices 7, 11, 13 (table-driven butterflies)
+    ((28, 6, 4), 2, 6, 64, 1e-12, {}),                       # 7 behind 4
 ])
 def test_size_generic_path_matches_oracle(oracle, shape, n_gl, n_sph, prec, tol, kw):
     """Grids outside the fused pipeline's cubes (csrc/bfsm_generic.hpp: one mixed-radix Stockham pass per axis, pointwise
