@@ -290,10 +290,13 @@ def main():
     op = make(False)
     # Set-up, not measurement: let the device reach its steady clock / page state before the W warm-up steps, so that
     # a short --steps run reports the same rate as a long one (a cold 5-step run read 6 % low).
+    # Queued in bursts, like the timed loop: an evaluation that starts after an idle gap (a host synchronisation) runs its
+    # first heavy kernel ~15 % slower, which would also colour a rocprofv3 --stats average of this command.
     t_pre = time.perf_counter()
     while time.perf_counter() - t_pre < 0.3:
-        op.computeCollisionAsync(Q, f, torch.cuda.current_stream().cuda_stream) if world == 1 else \
-            op.gainPartial(f, torch.cuda.current_stream().cuda_stream)
+        for _ in range(8):
+            op.computeCollisionAsync(Q, f, torch.cuda.current_stream().cuda_stream) if world == 1 else \
+                op.gainPartial(f, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
     if world > 1:
         # also set-up: RCCL builds its communicator / channels on the first collective of each kind; do that here so
@@ -345,11 +348,15 @@ def main():
         # Same regime as the timed loop: evaluations queued back to back, no host synchronisation between them; the
         # handle keeps the events of the LAST evaluation of a burst, which ran directly behind its predecessors (a
         # kernel that starts after an idle gap reads up to 15 % longer, so sum(per_kernel) would exceed ms_per_step).
-        reps, acc, burst = 5, None, 3
+        reps, acc, burst, burst_ms = 5, None, 3, 0.0
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for _ in range(reps):
+            ev0.record()
             for _ in range(burst):
                 profiled_eval()
+            ev1.record()
             torch.cuda.synchronize()
+            burst_ms += ev0.elapsed_time(ev1) / burst      # one PROFILED evaluation (its event records included)
             cn = opp.counters()
             cur = [(cn.kernel_ms[i], cn.kernel_alg_bytes[i], cn.kernel_launches[i]) for i in range(len(bfsm.KERNEL_NAMES))]
             acc = cur if acc is None else [(a[0] + b[0], a[1] + b[1], a[2] + b[2]) for a, b in zip(acc, cur)]
@@ -380,6 +387,9 @@ def main():
                     "launches_per_eval": launches // reps,
                     "per_kernel_regime": f"HIP events of the last of {burst} evaluations queued back to back, mean of {reps} bursts",
                     "per_kernel_sum_ms": sum(a[0] for a in acc) / reps,
+                    # a profiled evaluation carries two event records per launch, so it is slightly longer than ms_per_step;
+                    # the per-kernel times add up to no more than THIS figure
+                    "profiled_eval_ms": burst_ms / reps,
                     "per_kernel": {bfsm.KERNEL_NAMES[i]: {"ms_per_eval": acc[i][0] / reps,
                                                           "alg_GBps": (acc[i][1] / (acc[i][0] * 1e-3) / 1e9) if acc[i][0] > 0 else 0.0}
                                    for i in range(len(acc))}}

@@ -122,7 +122,11 @@ struct DevCtx {
 #pragma clang diagnostic ignored "-Wold-style-cast"
         gptr g = (gptr)(reinterpret_cast<const unsigned char*>(row));
         asm volatile("" : "+s"(g));          // keep the row pointer an SGPR pair of its own (no re-association)
+#ifdef BFSM_PLAIN_LOADS     // A/B builds (tools only): ordinary loads for the streamed scratch
+        const vec2 r = *(gvec)(g + byte_off);
+#else
         const vec2 r = __builtin_nontemporal_load((gvec)(g + byte_off));
+#endif
 #pragma clang diagnostic pop
         return cx<T>{r.x, r.y};
     }

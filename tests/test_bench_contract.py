@@ -76,6 +76,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     # the per-kernel HIP-event times are taken in the regime of the timed loop (evaluations queued back to back), so
     # they add up to no more than a step (3 %: the event records themselves, and a 3-step headline sample)
     assert abs(sum(k["ms_per_eval"] for k in r["per_kernel"].values()) - r["per_kernel_sum_ms"]) < 1e-9
+    assert r["per_kernel_sum_ms"] <= r["profiled_eval_ms"], (r["per_kernel_sum_ms"], r["profiled_eval_ms"])
     assert r["per_kernel_sum_ms"] <= 1.03 * d["ms_per_step"], (r["per_kernel_sum_ms"], d["ms_per_step"])
     rp = d["repeats"]
     assert rp["n"] == 5 and rp["min"] <= rp["median"] <= rp["max"] and 0.8 * d["value"] < rp["median"] < 1.25 * d["value"]

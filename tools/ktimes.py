@@ -32,6 +32,8 @@ for case in sys.argv[1:]:
     op.setPrecision(prec)
     op.setProfiling(True)
     op.setExactReductions(mode in "eh", hermitian=(mode == "h"))
+    if os.environ.get("BFSM_MAX_CHUNK"):          # experiments: directions resident at once
+        op.setMaxChunk(int(os.environ["BFSM_MAX_CHUNK"]))
     op.initialize()
     t0 = time.time()
     while time.time() - t0 < 0.5:

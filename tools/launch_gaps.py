@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Per-dispatch durations of the gain kernels from a rocprofv3 kernel trace, split by what preceded the dispatch.
+
+usage: launch_gaps.py <dir with *kernel_trace.csv>
+Answers "why does KA have a slow tail in the --stats summary of a bench session".  Three populations per kernel:
+  after idle : the evaluation it belongs to started within 25 ms after the GPU had been idle for >= 10 ms (a new handle
+               being created, the CPU baseline running, process start): the first ~6 evaluations after such a pause run
+               their first heavy kernel up to 35 % slower, decaying back over ~20 ms;
+  after gap  : steady state, but the evaluation started >= 20 us after the previous kernel ended (a host synchronisation
+               between evaluations: the blocking-call loop, the boundary of a profiled burst);
+  steady     : queued directly behind the previous evaluation (what `value` times).
+"""
+import csv
+import glob
+import re
+import statistics
+import sys
+
+KIND = {"5": "KA gain_inv", "6": "KB gain_line", "7": "KC gain_fwd", "11": "KB' acc", "13": "KB' acc_h"}
+d = sys.argv[1]
+import os
+f = max(glob.glob(d + "/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)      # the newest trace in the directory
+rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(f))))
+out = {}
+prev_end = None
+last_idle_end = None     # time at which the last long idle period ended
+cls = "after idle"
+for s, e, name in rows:
+    gap = (s - prev_end) / 1e3 if prev_end is not None else 1e12      # us
+    if gap >= 10e3:
+        last_idle_end = s
+    prev_end = max(prev_end or 0, e)
+    m = re.search(r"\(bfsm::K\)(\d+),", name)
+    if not m:
+        continue
+    if m.group(1) == "0":                      # F1a opens an evaluation: classify the whole evaluation here
+        if last_idle_end is not None and (s - last_idle_end) / 1e6 <= 25.0:
+            cls = "after idle"
+        elif gap >= 20.0:
+            cls = "after gap"
+        else:
+            cls = "steady"
+    if m.group(1) in KIND:
+        out.setdefault(KIND[m.group(1)], {}).setdefault(cls, []).append((e - s) / 1e3)
+print(f"kernel trace: {f.split('/')[-1]}")
+print("dispatch durations in us")
+for k in sorted(out):
+    for c in ("steady", "after gap", "after idle"):
+        v = out[k].get(c)
+        if not v:
+            continue
+        sd = statistics.pstdev(v) if len(v) > 1 else 0.0
+        print(f"{k:14s} {c:10s} n={len(v):4d} mean={statistics.mean(v):9.1f} min={min(v):9.1f} max={max(v):9.1f} sd={sd:7.1f}")
