@@ -69,3 +69,18 @@ def test_product_never_references_the_oracle():
             if fn.endswith((".py", ".hpp", ".hip", ".cpp", ".h", "Makefile")):
                 text = open(os.path.join(dirpath, fn), errors="ignore").read()
                 assert "oracle" not in text.lower().replace("test infrastructure", ""), os.path.join(dirpath, fn)
+
+
+def test_measured_tables_are_generated_from_profiles():
+    """DESIGN.md / README.md: the measured tables between the `measured:begin TAG` markers are exactly what
+    tools/design_tables.py derives from the committed files under profiles/ -- prose cannot drift from the evidence."""
+    import re
+    import subprocess
+    import sys
+    text = open(os.path.join(ROOT, "DESIGN.md")).read()
+    tags = re.findall(r"<!-- measured:begin (\w+) -->", text)
+    assert tags, "DESIGN.md carries no generated measurement block"
+    for tag in set(tags):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "design_tables.py"), tag, "--check"],
+                             capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
