@@ -704,6 +704,9 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
     // 1024-thread workgroup leaves 128 VGPRs for 2 x 64 of data (N = 128, fp64): there it is re-read every
     // iteration (a 256 KiB plane shared by the workgroups of the plane: L2 / Infinity Cache traffic).
     constexpr bool KEEP = keep_plane<N, T>();
+    // re-read geometries: f_hat points in flight per batch (the split-exchange geometry has 4 registers' worth of room;
+    // E = 24 has the transform's own registers free at that moment and few waves to hide the L2 latency behind)
+    constexpr int REREAD = split_tile<N, T>() ? 4 : 12;
     cx<T> fh[KEEP ? E : 1];
     const size_t bz = (size_t)ctx.bz();
     const cx<T>* src = prm.fhat + bz * N * N * N + (size_t)lxi * N * N;
@@ -864,7 +867,7 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
                     cx<T> fm;
                     if constexpr (KEEP) fm = fh[m]; else fm = src[(u + TT * m) * N + p];
                     v[m] = CONJ ? cmulc(fm, ph) : cmul(fm, ph);   // conj(alpha1) f_hat / G  :  alpha1 f_hat / G
-                    if constexpr (!KEEP) { if ((m & 3) == 3) ctx.sched_fence(); }   // at most 4 re-read points in flight
+                    if constexpr (!KEEP) { if ((m % REREAD) == REREAD - 1) ctx.sched_fence(); }   // at most REREAD re-read points in flight
                 }
                 fft_tile<N, +1, T, true>(v, lds, p, u, twr, ctx);
                 cx<T>* dst = (CONJ ? prm.a2 : prm.a1) + bz * prm.a_bstride + ((size_t)d * prm.planes + lxi) * N * N;
@@ -899,7 +902,7 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
                 cx<T> fm;
                 if constexpr (KEEP) fm = fh[m]; else fm = src[(u + TT * m) * N + p];
                 v[m] = conj ? cmulc(fm, ph) : cmul(fm, ph);   // conj(alpha1) f_hat / G  :  alpha1 f_hat / G
-                if constexpr (!KEEP) { if ((m & 3) == 3) ctx.sched_fence(); }   // at most 4 re-read points in flight
+                if constexpr (!KEEP) { if ((m % REREAD) == REREAD - 1) ctx.sched_fence(); }   // at most REREAD re-read points in flight
             }
             // L2 warm-up of the phase-table rows of the direction after next.  The tables are read with ordinary loads and
             // stay in L2 next to the nontemporal streams as long as they fit (<= ~4 MiB per XCD); for larger direction
@@ -1276,6 +1279,40 @@ BFSM_HD void body_gain_fwd(const GainFwdParams<T>& prm, Ctx& ctx) {
                 acc[m].y += w * v[m].y;
             }
         }
+    } else if constexpr (E >= 24 || (E >= 12 && sizeof(T) == 8)) {
+        // Few waves per CU (N = 48 in fp64 / N = 96: 3- and 6-wave workgroups, 12 / 24 points per thread; measured: N = 96
+        // fp64 KC 1.65 -> 0.85 ms, N = 48 fp64 0.160 -> 0.130 ms; N = 48 fp32 is faster rolled): the rolled loop would issue
+        // a direction's loads, drain them all, accumulate, and only then issue the next direction's.  The points are split
+        // into two halves with their own registers, and the loads of the next half are issued before the current one is
+        // accumulated, so half a direction's loads are in flight at every moment.
+        constexpr int H = E / 2;
+        auto row_of = [&](int d) { return prm.p + (size_t)ctx.bz() * prm.p_bstride + ((size_t)d * N + x) * N * N; };
+        auto load_half = [&](cx<T>* t, const cx<T>* src, int h) {
+#pragma unroll
+            for (int m = 0; m < H; ++m)
+                t[m] = ctx.template ld_stream_at<N % 64 == 0>(src + (u + TT * (h * H + m)) * N, (unsigned)p * (unsigned)sizeof(cx<T>));
+        };
+        auto add_half = [&](const cx<T>* t, T w, int h) {
+#pragma unroll
+            for (int m = 0; m < H; ++m) {
+                acc[h * H + m].x += w * t[m].x;
+                acc[h * H + m].y += w * t[m].y;
+            }
+        };
+        cx<T> t0[H], t1[H];
+        const int d_end = seg.d0 + seg.n;
+        if (seg.n > 0) load_half(t0, row_of(seg.d0), 0);
+        for (int d = seg.d0; d < d_end; ++d) {
+            const cx<T>* src = row_of(d);
+            const T w = prm.dirw[prm.dir0 + d];
+            load_half(t1, src, 1);
+            ctx.sched_fence();
+            add_half(t0, w, 0);
+            if (d + 1 < d_end) load_half(t0, row_of(d + 1), 0);
+            ctx.sched_fence();
+            add_half(t1, w, 1);
+        }
+        fft_tile<N, -1, T, false, kc_split<N, T>()>(acc, lds, p, u, twr, ctx);
     } else {
         for (int d = seg.d0; d < seg.d0 + seg.n; ++d) {
             const cx<T>* src = prm.p + (size_t)ctx.bz() * prm.p_bstride + ((size_t)d * N + x) * N * N;
