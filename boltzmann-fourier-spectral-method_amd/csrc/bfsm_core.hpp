@@ -141,6 +141,24 @@ struct SmallDft<3, SGN, T> {
         a[2] = {fmad(K, d.y, m.x), fmad(-K, d.x, m.y)};      // m - i K d
     }
 };
+// 5 points: the two symmetric / antisymmetric pairs (1,4), (2,3) combined with cos / sin of 2 pi / 5 and 4 pi / 5
+template <int SGN, typename T>
+struct SmallDft<5, SGN, T> {
+    static BFSM_HD void run(cx<T>* a) {
+        constexpr T C1 = (T)0.30901699437494742410, C2 = (T)-0.80901699437494742410;
+        constexpr T S1 = (T)(SGN * 0.95105651629515357212), S2 = (T)(SGN * 0.58778525229247312917);
+        const cx<T> a1 = cadd(a[1], a[4]), b1 = csub(a[1], a[4]), a2 = cadd(a[2], a[3]), b2 = csub(a[2], a[3]);
+        const cx<T> m1 = {fmad(C2, a2.x, fmad(C1, a1.x, a[0].x)), fmad(C2, a2.y, fmad(C1, a1.y, a[0].y))};
+        const cx<T> m2 = {fmad(C1, a2.x, fmad(C2, a1.x, a[0].x)), fmad(C1, a2.y, fmad(C2, a1.y, a[0].y))};
+        const cx<T> r1 = {-fmad(S2, b2.y, S1 * b1.y), fmad(S2, b2.x, S1 * b1.x)};      // i (S1 b1 + S2 b2)
+        const cx<T> r2 = {-fmad(-S1, b2.y, S2 * b1.y), fmad(-S1, b2.x, S2 * b1.x)};    // i (S2 b1 - S1 b2)
+        a[0] = cadd(a[0], cadd(a1, a2));
+        a[1] = cadd(m1, r1);
+        a[4] = csub(m1, r1);
+        a[2] = cadd(m2, r2);
+        a[3] = csub(m2, r2);
+    }
+};
 // Sizes N1 * N2 with coprime factors by the prime-factor (Good-Thomas) index maps: no twiddles between the two
 // stages, only compile-time permutations of registers.
 //   in:  n = (N2 n1 + N1 n2) mod N        out: k = (N2 (N2^-1 mod N1) k1 + N1 (N1^-1 mod N2) k2) mod N
@@ -173,6 +191,7 @@ struct SmallDftPfa {
 template <int SGN, typename T> struct SmallDft<6, SGN, T> { static BFSM_HD void run(cx<T>* a) { SmallDftPfa<2, 3, SGN, T>::run(a); } };
 template <int SGN, typename T> struct SmallDft<12, SGN, T> { static BFSM_HD void run(cx<T>* a) { SmallDftPfa<4, 3, SGN, T>::run(a); } };
 template <int SGN, typename T> struct SmallDft<24, SGN, T> { static BFSM_HD void run(cx<T>* a) { SmallDftPfa<8, 3, SGN, T>::run(a); } };
+template <int SGN, typename T> struct SmallDft<20, SGN, T> { static BFSM_HD void run(cx<T>* a) { SmallDftPfa<4, 5, SGN, T>::run(a); } };
 
 // The same DFT of R points whose INPUTS carry twiddle factors: x[j] is to be multiplied by w[j] first (w[0] = 1 when
 // FIRST_ONE).  w holds forward-table values exp(-i...); the backward transform (SGN = +1) uses their conjugates.  The
@@ -234,6 +253,9 @@ template <> struct Geo<128> { static constexpr int E = 16, T = 8; };
 // sizes with a factor 3: N = Q T^2 needs T = 4 (the radix-E step is a prime-factor 4 x 3 / 8 x 3 transform)
 template <> struct Geo<48>  { static constexpr int E = 12, T = 4; };
 template <> struct Geo<96>  { static constexpr int E = 24, T = 4; };
+template <> struct Geo<80>  { static constexpr int E = 20, T = 4; };    // prime-factor 4 x 5 register transform
+template <> struct Geo<24>  { static constexpr int E = 12, T = 2; };    // two threads per line (48-thread tiles)
+template <> struct Geo<40>  { static constexpr int E = 20, T = 2; };
 
 // columns per workgroup of the line (x-axis) kernels: a row of N, or a divisor of it that keeps runs >= 384 bytes
 constexpr int line_npl(int n) { return n <= 64 ? n : (n % 64 == 0 ? 64 : n / 2); }
@@ -284,8 +306,8 @@ constexpr size_t line_lds_bytes() { return (size_t)Wg<N>::LINE_LDS_ELEMS * sizeo
 template <int N, typename T>
 struct Twiddles {
     // not held either where they would be per-lane data (rows of N lanes that do not cover whole waves) of more than
-    // 16 registers' worth next to E = 24 points per thread (N = 96): re-read through the vector cache at every use
-    static constexpr bool HELD = !split_tile<N, T>() && !(N % 64 != 0 && Wg<N>::E >= 24);
+    // 16 registers' worth next to E >= 20 points per thread (N = 80, 96): re-read through the vector cache at every use
+    static constexpr bool HELD = !split_tile<N, T>() && !(N % 64 != 0 && Wg<N>::E >= 20);
     static constexpr int TT = Wg<N>::T, Q = Wg<N>::Q;
     cx<T> w[HELD ? (TT - 1) * Q : 1];
     const cx<T>* row;   // tw + 0
@@ -1279,8 +1301,8 @@ BFSM_HD void body_gain_fwd(const GainFwdParams<T>& prm, Ctx& ctx) {
                 acc[m].y += w * v[m].y;
             }
         }
-    } else if constexpr (E >= 24 || (E >= 12 && sizeof(T) == 8)) {
-        // Few waves per CU (N = 48 in fp64 / N = 96: 3- and 6-wave workgroups, 12 / 24 points per thread; measured: N = 96
+    } else if constexpr (E >= 20 || (E >= 12 && sizeof(T) == 8)) {
+        // Few waves per CU (N = 48 in fp64, N = 80, 96: 3- to 6-wave workgroups, 12 - 24 points per thread; measured: N = 96
         // fp64 KC 1.65 -> 0.85 ms, N = 48 fp64 0.160 -> 0.130 ms; N = 48 fp32 is faster rolled): the rolled loop would issue
         // a direction's loads, drain them all, accumulate, and only then issue the next direction's.  The points are split
         // into two halves with their own registers, and the loads of the next half are issued before the current one is

@@ -354,8 +354,11 @@ struct HipBackend {
         if (gx <= 0 || gy <= 0 || gz <= 0) return;
         switch (N) {
             case 16: launch_n<kind, 16, T>(gx, gy, gz, prm); break;
+            case 24: launch_n<kind, 24, T>(gx, gy, gz, prm); break;
             case 32: launch_n<kind, 32, T>(gx, gy, gz, prm); break;
+            case 40: launch_n<kind, 40, T>(gx, gy, gz, prm); break;
             case 48: launch_n<kind, 48, T>(gx, gy, gz, prm); break;
+            case 80: launch_n<kind, 80, T>(gx, gy, gz, prm); break;
             case 64: launch_n<kind, 64, T>(gx, gy, gz, prm); break;
             case 96: launch_n<kind, 96, T>(gx, gy, gz, prm); break;
             case 128: launch_n<kind, 128, T>(gx, gy, gz, prm); break;

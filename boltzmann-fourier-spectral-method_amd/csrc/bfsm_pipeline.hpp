@@ -65,7 +65,7 @@ inline double sincc_ref(double x) {
 // other supported grid on the size-generic path of bfsm_generic.hpp.
 inline bool fused_grid(const bfsm_desc& d) {
     const int N = d.nvx;
-    return d.nvx == d.nvy && d.nvx == d.nvz && (N == 16 || N == 32 || N == 48 || N == 64 || N == 96 || N == 128);
+    return d.nvx == d.nvy && d.nvx == d.nvz && (N == 16 || N == 24 || N == 32 || N == 40 || N == 48 || N == 64 || N == 80 || N == 96 || N == 128);
 }
 
 // An axis length the library has a transform for: even (the reference's mode tables need it,
@@ -166,10 +166,12 @@ inline PlanInfo make_plan(const bfsm_desc& d) {
             if (resident > 0 && resident % p.N == 0) {
                 const int unit = resident / p.N;
                 for (int extra = 0; extra < unit && (runs * cuts) % unit != 0; ++extra) ++cuts;
-            } else if (p.N == 48 || p.N == 96) {
+            } else if (p.N == 48 || p.N == 96 || p.N == 80 || p.N == 24 || p.N == 40) {
                 // sizes whose row count does not divide the resident set: among cuts .. cuts + 3 take the count that
-                // fills its rounds of resident workgroups best (N = 96: one / two 6-wave workgroups per CU; N = 48: four / eight)
-                const int res = p.N == 96 ? (p.precision == BFSM_F64 ? 256 : 512) : (p.precision == BFSM_F64 ? 1024 : 2048);
+                // fills its rounds of resident workgroups best (N = 96 / 80: one / two or three workgroups per CU by LDS;
+                // N = 48: four / eight; N = 24: one-wave workgroups, 16 per CU)
+                const bool f64 = p.precision == BFSM_F64;
+                const int res = p.N == 96 ? (f64 ? 256 : 512) : p.N == 80 ? (f64 ? 256 : 768) : p.N == 48 ? (f64 ? 1024 : 2048) : (p.N == 40 ? 2048 : 4096);
                 int best = cuts;
                 double best_u = 0;
                 for (int c2 = cuts; c2 <= cuts + 3; ++c2) {

@@ -85,8 +85,8 @@ typedef struct bfsm_plan* bfsm_handle;
  */
 typedef struct bfsm_desc {
     int nvx, nvy, nvz;        /* velocity grid: every extent even, in [4, 256], prime factors 2, 3, 5, 7, 11, 13 (the
-                                 reference plans any Nvx x Nvy x Nvz, CUDABoltzmannOperator.cu:86-100).  Cubes of 16, 32,
-                                 48, 64, 96, 128 run on the fused pipeline (6 array passes per direction); every other box
+                                 reference plans any Nvx x Nvy x Nvz, CUDABoltzmannOperator.cu:86-100).  Cubes of 16, 24, 32,
+                                 40, 48, 64, 80, 96, 128 run on the fused pipeline (6 array passes per direction); every other box
                                  on the size-generic path (one transform pass per axis, several times slower), both
                                  precisions.  Anything else: BFSM_ERR_UNSUPPORTED */
     int n_gl;                 /* Gauss-Legendre points (radial)          */

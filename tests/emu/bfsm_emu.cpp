@@ -230,8 +230,11 @@ struct EmuBackend {
     void launch(int gx, int gy, int gz, const P& prm, int N) {
         switch (N) {
             case 16: launch_n<kind, 16, T>(gx, gy, gz, prm); break;
+            case 24: launch_n<kind, 24, T>(gx, gy, gz, prm); break;
             case 32: launch_n<kind, 32, T>(gx, gy, gz, prm); break;
+            case 40: launch_n<kind, 40, T>(gx, gy, gz, prm); break;
             case 48: launch_n<kind, 48, T>(gx, gy, gz, prm); break;
+            case 80: launch_n<kind, 80, T>(gx, gy, gz, prm); break;
             case 64: launch_n<kind, 64, T>(gx, gy, gz, prm); break;
             case 96: launch_n<kind, 96, T>(gx, gy, gz, prm); break;
             case 128: launch_n<kind, 128, T>(gx, gy, gz, prm); break;
@@ -364,7 +367,7 @@ int bfsm_emu_finish(const bfsm_desc* d, const double* f, const double* qhat_in, 
 
 // Emulated bfsm_fft3d; data = batch*G interleaved complex doubles (narrowed to float when precision == 32).
 int bfsm_emu_fft3d(int N, int precision, double* data, int batch, int sign) {
-    if (N != 16 && N != 32 && N != 48 && N != 64 && N != 96 && N != 128) return BFSM_ERR_UNSUPPORTED;
+    if (N != 16 && N != 24 && N != 32 && N != 40 && N != 48 && N != 64 && N != 80 && N != 96 && N != 128) return BFSM_ERR_UNSUPPORTED;
     if (precision == BFSM_F64) return emu::fft3d_t<double>(N, data, batch, sign);
     return emu::fft3d_t<float>(N, data, batch, sign);
 }

@@ -51,7 +51,7 @@ def collide(f, gl, sph, gamma, b_gamma, L, precision=64, dir_range=(0, 0), max_c
     if rc:
         raise RuntimeError(f"bfsm_emu_collide rc={rc}")
     qhat_t = qh[..., 0] + 1j * qh[..., 1]            # fused pipeline: [lx][lz][ly]; size-generic path: natural
-    if np.isscalar(nv) and nv in (16, 32, 48, 64, 96, 128):
+    if np.isscalar(nv) and nv in (16, 24, 32, 40, 48, 64, 80, 96, 128):
         qhat_t = np.ascontiguousarray(qhat_t.transpose(0, 2, 1))   # -> [lx][ly][lz]
     return (Q if want_Q else None), qhat_t
 

@@ -15,7 +15,8 @@ GAMMA, B_GAMMA, R = 0.0, 1.0 / (4.0 * np.pi), 10.0
 
 @pytest.mark.parametrize("n,prec,tol", [(16, 64, 2e-15), (32, 64, 2e-15), (64, 64, 3e-15), (16, 32, 1e-6),
                                         (32, 32, 1e-6), (64, 32, 1e-6), (128, 32, 1e-6), (128, 64, 3e-15),
-                                        (48, 64, 3e-15), (96, 64, 3e-15), (48, 32, 1e-6), (96, 32, 1e-6)])
+                                        (48, 64, 3e-15), (96, 64, 3e-15), (48, 32, 1e-6), (96, 32, 1e-6),
+                                        (24, 64, 3e-15), (80, 64, 3e-15), (80, 32, 1e-6)])
 def test_fft3d_matches_numpy_and_round_trips(n, prec, tol):
     """Mirrors the reference's FFT check (fftw_benchmark.cpp:137-171): forward, scale 1/G, inverse."""
     rng = np.random.default_rng(n + prec)
@@ -30,7 +31,7 @@ def test_fft3d_matches_numpy_and_round_trips(n, prec, tol):
 
 @pytest.mark.parametrize("nv,n_gl,n_sph,max_chunk,prec,tol", [
     (16, 2, 6, 0, 64, 1e-12), (16, 3, 12, 5, 64, 1e-12), (32, 2, 6, 4, 64, 1e-12), (16, 2, 6, 0, 32, 2e-5),
-    (48, 2, 6, 5, 64, 1e-12), (48, 1, 6, 0, 32, 1e-4), (96, 1, 6, 0, 64, 1e-12),      # radix-3 geometries (E = 12 / 24, T = 4); fp32: Q = gain - loss cancels on a 6-direction rule
+    (48, 2, 6, 5, 64, 1e-12), (48, 1, 6, 0, 32, 1e-4), (96, 1, 6, 0, 64, 1e-12), (80, 1, 6, 0, 64, 1e-12), (24, 3, 12, 5, 64, 1e-12), (40, 2, 6, 0, 64, 1e-12),      # radix-3 geometries (E = 12 / 24, T = 4); fp32: Q = gain - loss cancels on a 6-direction rule
 ])
 def test_collide_matches_oracle(oracle, nv, n_gl, n_sph, max_chunk, prec, tol):
     f, _, L, _ = oracle.bkw(nv)
@@ -216,7 +217,7 @@ HERMITIAN = 4   # BFSM_FLAG_HERMITIAN (only together with EXACT)
 
 
 @pytest.mark.parametrize("nv,n_gl,n_sph,max_chunk", [(16, 3, 12, 0), (16, 3, 12, 5), (32, 2, 6, 0), (48, 2, 6, 0),
-                                                     (96, 1, 6, 0)])
+                                                     (96, 1, 6, 0), (80, 1, 6, 0), (24, 3, 12, 0), (40, 2, 6, 0)])
 def test_hermitian_reduction_matches_oracle(oracle, nv, n_gl, n_sph, max_chunk):
     """f real => A'[-lx] = conj A'[lx] + exact rank-one Nyquist terms: only the planes lx = 0..N/2 are computed and
     stored.  The perturbed input has energy in all three Nyquist planes, so a wrong correction shows at 1e-3."""
@@ -313,6 +314,7 @@ def test_randomised_plans_against_the_oracle(oracle):
 @pytest.mark.parametrize("shape,n_gl,n_sph,prec,tol,kw", [
     ((8, 4, 12), 3, 12, 64, 1e-12, {}),                      # non-cubic, radix 2 / 4 / 3
     ((12, 12, 12), 2, 6, 64, 1e-12, {}),                     # cubic but not a fused size (radix 3)
+    ((20, 20, 20), 1, 6, 64, 1e-12, {}),                     # cubic, radix 5, not a fused size
     ((20, 10, 4), 2, 6, 64, 1e-12, {}),                      # radix 5
     ((16, 8, 6), 3, 12, 64, 1e-12, {"max_chunk": 5}),        # several chunks of directions
     ((16, 8, 6), 3, 12, 64, 1e-12, {"dir_range": (7, 29)}),  # a direction shard

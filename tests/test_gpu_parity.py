@@ -1065,11 +1065,12 @@ def test_batch_of_one_equals_a_single_evaluation_bitwise(torch_cuda):
 
 
 @pytest.mark.parametrize("mode", ["faithful", "exact", "hermitian"])
-@pytest.mark.parametrize("nv,n_gl,n_sph,prec", [(48, 4, 12, 64), (96, 2, 12, 64), (48, 4, 12, 32), (96, 2, 12, 32)])
+@pytest.mark.parametrize("nv,n_gl,n_sph,prec", [(48, 4, 12, 64), (96, 2, 12, 64), (48, 4, 12, 32), (96, 2, 12, 32),
+                                                (80, 2, 12, 64), (80, 2, 12, 32), (24, 4, 12, 64), (40, 4, 12, 64)])
 def test_fused_radix3_sizes_match_oracle(torch_cuda, oracle, nv, n_gl, n_sph, prec, mode):
-    """N = 48 and N = 96 on the fused three-kernel pipeline (12 / 24 points per thread, prime-factor 4 x 3 / 8 x 3
-    register transforms, 4 threads per line): whole field on the perturbed input against the oracle, all three modes,
-    both precisions; plus a direction shard pair and a batch member."""
+    """N = 48, 96 (prime-factor 4 x 3 / 8 x 3 register transforms, 4 threads per line), N = 80 (4 x 5) and N = 24 (two
+    threads per line) on the fused three-kernel pipeline: whole field on the perturbed input against the oracle, all
+    three modes, both precisions; plus a direction shard pair."""
     import bfsm
     torch = torch_cuda
     f_h, ref = _full_ref(oracle, nv, n_gl, n_sph)
