@@ -70,6 +70,22 @@ def test_collide_n128_fp64_matches_oracle(oracle):
     assert np.abs(Q - Qo).max() <= 1e-12 * np.abs(Qo).max()
 
 
+@pytest.mark.slow
+def test_collide_n128_fp32_pipelined_pair_matches_oracle(oracle):
+    """N = 128 in single precision: KA processes the two signs of a direction as a software-pipelined pair of tiles
+    through one exchange buffer (12 barriers per direction).  The emulator advances the waves adversarially, so a
+    missing barrier between a read phase of one tile and the write phase of the other reads stale LDS here (6-point
+    design, one radial node: every workgroup column loops over several directions, so the hand-over of the exchange
+    buffer from one direction to the next is covered as well)."""
+    f, _, L, _ = oracle.bkw(128)
+    f = oracle.perturbed_input(f)
+    gl = oracle.gauss_legendre(1, 0.0, R)
+    sph = oracle.spherical_design(6)
+    Q, qhat = E.collide(f, gl, sph, GAMMA, B_GAMMA, L, 32)
+    Qo, qo = oracle.collide(f, gl, sph, GAMMA, B_GAMMA, L, return_qhat=True)
+    assert np.abs(qhat - qo).max() <= 2e-5 * np.abs(qo).max()           # fp32 rounding: measured 7.6e-6
+
+
 def test_direction_shards_add_up(oracle):
     """Partial Q_gain_hat of disjoint shards (what each GPU contributes to the reduce) sums to the whole."""
     f, _, L, _ = oracle.bkw(16)
