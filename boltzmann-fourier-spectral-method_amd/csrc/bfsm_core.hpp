@@ -749,6 +749,7 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
         // ("|" = barrier; 12 per direction instead of 14).  The phase factors are formed once per point and used for both
         // signs (the two tiles are live together here anyway).  Measured against the sequential form: see DESIGN.md 7.1.
         constexpr int Q = Wg<N>::Q, LS = Wg<N>::LS;
+        unsigned pl = (unsigned)p * (unsigned)sizeof(cx<T>);   // this lane's byte offset inside a row
         auto xw_line = [&](const cx<T>* v) {
 #pragma unroll
             for (int k1 = 0; k1 < E; ++k1) ctx.lds_st(lds + (k1 * TT + u) * LS + p, v[k1]);
@@ -780,7 +781,7 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
                 SmallDftTw<TT, +1, T, true>::run(w2 + q * TT, w);
 #pragma unroll
                 for (int k2 = 0; k2 < TT; ++k2)   // row y = u + T (q + Q k2), z = p
-                    ctx.template st_stream_at<N % 64 == 0>(dst + (size_t)(u + TT * (q + Q * k2)) * N, (unsigned)p * (unsigned)sizeof(cx<T>), w2[q * TT + k2]);
+                    ctx.template st_stream_at<N % 64 == 0>(dst + (size_t)(u + TT * (q + Q * k2)) * N, pl, w2[q * TT + k2]);
 #ifndef BFSM_KA_STORE_BURST
                 ctx.sched_fence();
 #endif
@@ -801,6 +802,7 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
                 const cx<T>* row = (l < LINES) ? prm.phz : prm.phy;
                 warm = row[bw * N + (size_t)(l % LINES) * EPL].x;
             }
+            pl = ctx.lane_off((unsigned)p * (unsigned)sizeof(cx<T>));     // per-iteration copy, see DevCtx::lane_off
             cx<T> va[E], vb[E], wa[E], wb[E];
 #ifdef BFSM_KA_SHARE_PHASE
             constexpr bool SHARE = true;        // phase factors formed once for both signs: 64 operations fewer, 32 more
@@ -893,9 +895,10 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
                 }
                 fft_tile<N, +1, T, true>(v, lds, p, u, twr, ctx);
                 cx<T>* dst = (CONJ ? prm.a2 : prm.a1) + bz * prm.a_bstride + ((size_t)d * prm.planes + lxi) * N * N;
+                const unsigned pl = ctx.lane_off((unsigned)p * (unsigned)sizeof(cx<T>));    // per iteration: see DevCtx::lane_off
 #pragma unroll
                 for (int m = 0; m < E; ++m)   // [y = u + T m][z = p]
-                    ctx.template st_stream_at<N % 64 == 0>(dst + (size_t)(u + TT * m) * N, (unsigned)p * (unsigned)sizeof(cx<T>), v[m]);
+                    ctx.template st_stream_at<N % 64 == 0>(dst + (size_t)(u + TT * m) * N, pl, v[m]);
             };
             one_sign(BoolTag<false>{});
             if (warming) ctx.keep_alive(warm);
@@ -945,9 +948,10 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
             fft_tile<N, +1, T>(v, lds, p, u, twr, ctx);
             if (warming) ctx.keep_alive(warm);
             cx<T>* dst = (conj ? prm.a2 : prm.a1) + bz * prm.a_bstride + ((size_t)d * prm.planes + lxi) * N * N;
+            const unsigned pl = ctx.lane_off((unsigned)p * (unsigned)sizeof(cx<T>));
 #pragma unroll
             for (int m = 0; m < E; ++m)   // [y = u + T m][z = p]
-                ctx.template st_stream_at<N % 64 == 0>(dst + (size_t)(u + TT * m) * N, (unsigned)p * (unsigned)sizeof(cx<T>), v[m]);
+                ctx.template st_stream_at<N % 64 == 0>(dst + (size_t)(u + TT * m) * N, pl, v[m]);
         }
     }
 }

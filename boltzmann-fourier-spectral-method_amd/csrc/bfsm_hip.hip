@@ -45,6 +45,13 @@ struct DevCtx {
         asm volatile("" : "+v"(v));
         return v;
     }
+    // Lane byte offset of the row accessors below, re-materialised where it is called (inside a loop): hoisted out of
+    // the loop as a zero-extended 64-bit value it defeats the saddr + voffset addressing form (one 64-bit VALU add and a
+    // VGPR pair per access instead)
+    __device__ __forceinline__ unsigned lane_off(unsigned v) const {
+        asm volatile("" : "+v"(v));
+        return v;
+    }
     // a per-lane value the optimiser may not trace back to its origin (no common-subexpression sharing through it)
     template <class T>
     __device__ __forceinline__ cx<T> opaque_cx(cx<T> v) const {

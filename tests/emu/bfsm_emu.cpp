@@ -52,6 +52,7 @@ struct EmuCtx {
     void sched_fence() const {}   // compiler scheduling hint on the device; nothing to do on the host
     int opaque(int v) const { return v; }
     int opaque_v(int v) const { return v; }
+    unsigned lane_off(unsigned v) const { return v; }
     template <class U> U opaque_cx(U v) const { return v; }
     template <class T> void keep_alive(T) const {}
     template <class U> U* uniform_ptr(U* p) const { return p; }
