@@ -260,24 +260,42 @@ template <> struct Geo<40>  { static constexpr int E = 20, T = 2; };
 // columns per workgroup of the line (x-axis) kernels: a row of N, or a divisor of it that keeps runs >= 384 bytes
 constexpr int line_npl(int n) { return n <= 64 ? n : (n % 64 == 0 ? 64 : n / 2); }
 
+// Lanes per row of threads.  Rows that do not cover whole waves are padded to the next multiple of 64 lanes at N = 40,
+// 48 and 96 (and their line-kernel column counts); a padding lane DUPLICATES the lane (ROW - N) below it -- same
+// addresses, same values, everywhere -- so no access needs a guard, and every wave has ONE u: twiddles and phase factors
+// become scalar loads as at N = 64 / 128 instead of per-lane vector loads (N = 96: 84 of them per tile and thread).
+// Costs 25 - 37 % duplicate lanes.  Measured, 384 directions fp64, padded against unpadded: 96^3 8.02 / 8.51 ms (KB 2.93 /
+// 3.53), 40^3 0.543 / 0.570, 48^3 0.818 / 0.803 (Hermitian mode 0.298 / 0.418); 80^3 4.90 / 4.45 ms: not padded.
+constexpr int row_pad(int n) { return (n == 40 || n == 48) ? 64 : (n == 96 ? 128 : n); }
+
 template <int N>
 struct Wg {
     static constexpr int E = Geo<N>::E;
     static constexpr int T = Geo<N>::T;
     static constexpr int Q = E / T;           // radix-T sub-transforms per thread in the second step
-    static constexpr int THREADS = N * T;     // one N x N tile per workgroup
+    static constexpr int ROW = row_pad(N);    // lanes per tile row (>= N)
+    static constexpr int THREADS = ROW * T;   // one N x N tile per workgroup
     static constexpr int LS = N + 1;          // LDS row stride (elements); odd => transposed reads conflict-free
     static constexpr int LDS_ELEMS = N * LS;
     // Line kernels (1-D passes along x) only need a set of independent columns, not a whole tile: they take NPL
     // columns per workgroup.  At N = 128 that is half a row, which halves the exchange buffer (66 KiB in fp32) and
     // lets two workgroups share a CU; the 2-D tile kernels keep N columns.
     static constexpr int NPL = line_npl(N);
-    static constexpr int LINE_THREADS = NPL * T;
+    static constexpr int LROW = row_pad(NPL); // lanes per row of a line kernel (>= NPL)
+    static constexpr int LINE_THREADS = LROW * T;
     // N rows for the exchanges; N + 2 so that the Hermitian line kernel can stage the stored halves (N/2 + 1 rows) of
     // both arrays side by side
     static constexpr int LINE_LDS_ELEMS = (N + 2) * (NPL + 1);
     static_assert(E * T == N && Q * T == E && N % NPL == 0, "geometry");
 };
+
+// (column p, line share u) of this thread in a row of ROWW lanes serving W columns (see row_pad)
+template <int W, int ROWW, class Ctx>
+BFSM_HD void lane_coords(Ctx& ctx, int& p, int& u) {
+    const int tid = ctx.tid(), pr = tid % ROWW;
+    u = ctx.uniform(tid / ROWW, ROWW);
+    p = (ROWW == W || pr < W) ? pr : pr - (ROWW - W);
+}
 
 // A whole N x N tile of complex T must fit the CU's 160 KiB LDS for the exchanges of the 2-D tile kernels.  The one
 // geometry where it does not (N = 128 in fp64: 258 KiB) exchanges the real and the imaginary parts one after the
@@ -305,9 +323,9 @@ constexpr size_t line_lds_bytes() { return (size_t)Wg<N>::LINE_LDS_ELEMS * sizeo
 // spill) only the table position is kept and every use is a fresh scalar load from the constant cache.
 template <int N, typename T>
 struct Twiddles {
-    // not held either where they would be per-lane data (rows of N lanes that do not cover whole waves) of more than
-    // 16 registers' worth next to E >= 20 points per thread (N = 80, 96): re-read through the vector cache at every use
-    static constexpr bool HELD = !split_tile<N, T>() && !(N % 64 != 0 && Wg<N>::E >= 20);
+    // not held either with E >= 20 points per thread (N = 40, 80, 96: 15 - 18 complex factors next to the transform's
+    // own registers): re-read at every use (scalar loads where a row of threads covers whole waves, see row_pad)
+    static constexpr bool HELD = !split_tile<N, T>() && Wg<N>::E < 20;
     static constexpr int TT = Wg<N>::T, Q = Wg<N>::Q;
     cx<T> w[HELD ? (TT - 1) * Q : 1];
     const cx<T>* row;   // tw + 0
@@ -328,7 +346,7 @@ struct Twiddles {
     BFSM_HD cx<T> get(int q, int uu, Ctx& ctx) const {
         if constexpr (HELD) return w[q * (TT - 1) + uu - 1];
         else {                                    // opaque: keeps the load where it is used (no hoisting out of the loops)
-            const int uo = (N % 64 == 0) ? ctx.opaque(u) : ctx.opaque_v(u);
+            const int uo = (Wg<N>::ROW % 64 == 0) ? ctx.opaque(u) : ctx.opaque_v(u);
             return ctx.ldc(row + ((uu * (uo + TT * q)) % N));
         }
     }
@@ -643,7 +661,8 @@ template <bool B> struct BoolTag { static constexpr bool value = B; };
 template <int N, typename T, class Ctx>
 BFSM_HD void body_tile_fwd_real(const TileFwdRealParams<T>& prm, Ctx& ctx) {
     constexpr int E = Wg<N>::E, TT = Wg<N>::T;
-    const int tid = ctx.tid(), p = tid % N, u = ctx.uniform(tid / N, N);
+    int p, u;
+    lane_coords<N, Wg<N>::ROW>(ctx, p, u);
     const int x = ctx.bx();
     const size_t boff = (size_t)ctx.by() * N * N * N;      // batch member
     cx<T>* lds = ctx.template lds<cx<T>>();
@@ -664,7 +683,8 @@ BFSM_HD void body_tile_fwd_real(const TileFwdRealParams<T>& prm, Ctx& ctx) {
 template <int N, int SGN, typename T, class Ctx>
 BFSM_HD void body_tile_c2c(const LineParams<T>& prm, Ctx& ctx) {
     constexpr int E = Wg<N>::E, TT = Wg<N>::T;
-    const int tid = ctx.tid(), p = tid % N, u = ctx.uniform(tid / N, N);
+    int p, u;
+    lane_coords<N, Wg<N>::ROW>(ctx, p, u);
     const size_t base = ((size_t)ctx.by() * N + ctx.bx()) * N * N;
     cx<T>* lds = ctx.template lds<cx<T>>();
     Twiddles<N, T> twr;
@@ -683,7 +703,8 @@ template <int N, int SGN, typename T, class Ctx>
 BFSM_HD void body_line(const LineParams<T>& prm, Ctx& ctx) {
     constexpr int E = Wg<N>::E, TT = Wg<N>::T;
     constexpr int NPL = Wg<N>::NPL;
-    const int tid = ctx.tid(), p = tid % NPL, u = ctx.uniform(tid / NPL, NPL);   // p: column inside this block of NPL
+    int p, u;                                   // p: column inside this block of NPL
+    lane_coords<NPL, Wg<N>::LROW>(ctx, p, u);
     const size_t base = (size_t)ctx.by() * N * N * N + (size_t)ctx.bx() * NPL + p;
     cx<T>* lds = ctx.template lds<cx<T>>();
     Twiddles<N, T> twr;
@@ -717,7 +738,9 @@ template <int N, typename T> constexpr bool pipelined_pair() {
 template <int N, typename T, class Ctx>
 BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
     constexpr int E = Wg<N>::E, TT = Wg<N>::T;
-    const int tid = ctx.tid(), p = tid % N, u = ctx.uniform(tid / N, N);
+    int p, u;
+    lane_coords<N, Wg<N>::ROW>(ctx, p, u);
+    const int tid = ctx.tid();
     const int lxi = ctx.bx();
     cx<T>* lds = ctx.template lds<cx<T>>();
     Twiddles<N, T> twr;
@@ -781,7 +804,7 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
                 SmallDftTw<TT, +1, T, true>::run(w2 + q * TT, w);
 #pragma unroll
                 for (int k2 = 0; k2 < TT; ++k2)   // row y = u + T (q + Q k2), z = p
-                    ctx.template st_stream_at<N % 64 == 0>(dst + (size_t)(u + TT * (q + Q * k2)) * N, pl, w2[q * TT + k2]);
+                    ctx.template st_stream_at<Wg<N>::ROW % 64 == 0>(dst + (size_t)(u + TT * (q + Q * k2)) * N, pl, w2[q * TT + k2]);
 #ifndef BFSM_KA_STORE_BURST
                 ctx.sched_fence();
 #endif
@@ -898,7 +921,7 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
                 const unsigned pl = ctx.lane_off((unsigned)p * (unsigned)sizeof(cx<T>));    // per iteration: see DevCtx::lane_off
 #pragma unroll
                 for (int m = 0; m < E; ++m)   // [y = u + T m][z = p]
-                    ctx.template st_stream_at<N % 64 == 0>(dst + (size_t)(u + TT * m) * N, pl, v[m]);
+                    ctx.template st_stream_at<Wg<N>::ROW % 64 == 0>(dst + (size_t)(u + TT * m) * N, pl, v[m]);
             };
             one_sign(BoolTag<false>{});
             if (warming) ctx.keep_alive(warm);
@@ -951,7 +974,7 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
             const unsigned pl = ctx.lane_off((unsigned)p * (unsigned)sizeof(cx<T>));
 #pragma unroll
             for (int m = 0; m < E; ++m)   // [y = u + T m][z = p]
-                ctx.template st_stream_at<N % 64 == 0>(dst + (size_t)(u + TT * m) * N, pl, v[m]);
+                ctx.template st_stream_at<Wg<N>::ROW % 64 == 0>(dst + (size_t)(u + TT * m) * N, pl, v[m]);
         }
     }
 }
@@ -1025,14 +1048,15 @@ template <int N, typename T, class Ctx>
 BFSM_HD void body_gain_line(const GainLineParams<T>& prm, Ctx& ctx) {
     constexpr int E = Wg<N>::E, TT = Wg<N>::T;
     constexpr int NPL = Wg<N>::NPL;
-    const int tid = ctx.tid(), p = tid % NPL, u = ctx.uniform(tid / NPL, NPL);   // p: column inside this block of NPL
+    int p, u;                                   // p: column inside this block of NPL
+    lane_coords<NPL, Wg<N>::LROW>(ctx, p, u);
     // wave-uniform row pointers + a 32-bit lane offset: the accesses take the scalar-base addressing form, so no
     // per-access 64-bit address lives in VGPRs
     const size_t ubase = (size_t)ctx.bz() * prm.a_bstride + (size_t)ctx.by() * N * N * N + (size_t)ctx.bx() * NPL;
     cx<T>* A1 = prm.a1 + ubase;
     const cx<T>* A2 = prm.a2 + ubase;
     const unsigned pl = (unsigned)p * (unsigned)sizeof(cx<T>);   // lane offset in bytes
-    constexpr bool UNI = NPL % 64 == 0;
+    constexpr bool UNI = Wg<N>::LROW % 64 == 0;
     cx<T>* lds = ctx.template lds<cx<T>>();
     Twiddles<N, T> twr;
     twr.load(prm.tw, u, ctx);
@@ -1058,14 +1082,15 @@ template <int N, typename T, class Ctx>
 BFSM_HD void body_gain_line_acc(const GainLineAccParams<T>& prm, Ctx& ctx) {
     constexpr int E = Wg<N>::E, TT = Wg<N>::T;
     constexpr int NPL = Wg<N>::NPL;
-    const int tid = ctx.tid(), p = tid % NPL, u = ctx.uniform(tid / NPL, NPL);   // p: column inside this block of NPL
+    int p, u;                                   // p: column inside this block of NPL
+    lane_coords<NPL, Wg<N>::LROW>(ctx, p, u);
     cx<T>* lds = ctx.template lds<cx<T>>();
     Twiddles<N, T> twr;
     twr.load(prm.tw, u, ctx);
     const Segment seg = prm.segs[prm.seg0 + ctx.by()];
     const size_t row = (size_t)ctx.bx() * NPL;                   // uniform; the lane adds pl bytes
     const unsigned pl = (unsigned)p * (unsigned)sizeof(cx<T>);
-    constexpr bool UNI = NPL % 64 == 0;
+    constexpr bool UNI = Wg<N>::LROW % 64 == 0;
     cx<T> acc[E];
 #pragma unroll
     for (int m = 0; m < E; ++m) acc[m] = {(T)0, (T)0};
@@ -1098,7 +1123,8 @@ BFSM_HD void body_gain_line_acc(const GainLineAccParams<T>& prm, Ctx& ctx) {
 template <int N, typename T, class Ctx>
 BFSM_HD void body_nyq_rows(const NyqRowsParams<T>& prm, Ctx& ctx) {
     constexpr int E = Wg<N>::E, TT = Wg<N>::T, NPL = Wg<N>::NPL, NQ = N / 2 - 1, H = N / 2;
-    const int tid = ctx.tid(), p = tid % NPL, u = ctx.uniform(tid / NPL, NPL);
+    int p, u;
+    lane_coords<NPL, Wg<N>::LROW>(ctx, p, u);
     cx<T>* lds = ctx.template lds<cx<T>>();
     Twiddles<N, T> twr;
     twr.load(prm.tw, u, ctx);
@@ -1149,7 +1175,7 @@ template <int N, typename T, class Ctx>
 BFSM_HD void hermitian_lines_load(cx<T>* a, cx<T>* b, const cx<T>* A1, const cx<T>* A2, int colrow, unsigned pl, int p,
                                   int u, cx<T>* lds, Ctx& ctx) {
     constexpr int E = Wg<N>::E, TT = Wg<N>::T, MS = E / 2, LS = Wg<N>::NPL + 1, H = N / 2;
-    constexpr bool UNI = Wg<N>::NPL % 64 == 0;
+    constexpr bool UNI = Wg<N>::LROW % 64 == 0;
     static_assert(TT * MS == N / 2, "split row");
     cx<T>* ha = lds;
     cx<T>* hb = lds + (H + 1) * LS;
@@ -1183,7 +1209,7 @@ BFSM_HD void hermitian_lines_load(cx<T>* a, cx<T>* b, const cx<T>* A1, const cx<
 template <int N, typename T, class Ctx>
 BFSM_HD void hermitian_line_load1(cx<T>* a, const cx<T>* A1, int colrow, unsigned pl, int p, int u, cx<T>* lds, Ctx& ctx) {
     constexpr int E = Wg<N>::E, TT = Wg<N>::T, MS = E / 2, LS = Wg<N>::NPL + 1, H = N / 2;
-    constexpr bool UNI = Wg<N>::NPL % 64 == 0;
+    constexpr bool UNI = Wg<N>::LROW % 64 == 0;
 #pragma unroll
     for (int m = 0; m < MS; ++m) a[m] = ctx.template ld_stream_at<UNI>(A1 + (size_t)(u + TT * m) * N * N + colrow, pl);
     if (u == 0) a[MS] = ctx.template ld_stream_at<UNI>(A1 + (size_t)H * N * N + colrow, pl);
@@ -1216,7 +1242,8 @@ BFSM_HD void hermitian_line_fix(cx<T>* v, const cx<T>* R, int y, int z0, int p, 
 template <int N, typename T, class Ctx>
 BFSM_HD void body_gain_line_acc_h(const GainLineAccHParams<T>& prm, Ctx& ctx) {
     constexpr int E = Wg<N>::E, TT = Wg<N>::T, NPL = Wg<N>::NPL, NQ = N / 2 - 1, NH = N / 2 + 1;
-    const int tid = ctx.tid(), p = tid % NPL, u = ctx.uniform(tid / NPL, NPL);
+    int p, u;
+    lane_coords<NPL, Wg<N>::LROW>(ctx, p, u);
     cx<T>* lds = ctx.template lds<cx<T>>();
     Twiddles<N, T> twr;
     twr.load(prm.tw, u, ctx);
@@ -1262,7 +1289,7 @@ BFSM_HD void body_gain_line_acc_h(const GainLineAccHParams<T>& prm, Ctx& ctx) {
     const size_t obase = (size_t)ctx.bz() * prm.pseg_bstride + (size_t)(prm.seg0 + gby) * N * N * N + colrow;
 #pragma unroll
     for (int m = 0; m < E; ++m)
-        ctx.template st_at<NPL % 64 == 0>(prm.pseg + obase + (size_t)(u + TT * m) * N * N, pl, acc[m]);
+        ctx.template st_at<Wg<N>::LROW % 64 == 0>(prm.pseg + obase + (size_t)(u + TT * m) * N * N, pl, acc[m]);
 }
 
 // KC.  grid = (N planes x, segments of the chunk).  (y,z) part of the forward transform + the direction sum of
@@ -1276,7 +1303,8 @@ BFSM_HD void body_gain_line_acc_h(const GainLineAccHParams<T>& prm, Ctx& ctx) {
 template <int N, typename T, class Ctx>
 BFSM_HD void body_gain_fwd(const GainFwdParams<T>& prm, Ctx& ctx) {
     constexpr int E = Wg<N>::E, TT = Wg<N>::T;
-    const int tid = ctx.tid(), p = tid % N, u = ctx.uniform(tid / N, N);
+    int p, u;
+    lane_coords<N, Wg<N>::ROW>(ctx, p, u);
     const int x = ctx.bx();
     cx<T>* lds = ctx.template lds<cx<T>>();
     Twiddles<N, T> twr;
@@ -1296,7 +1324,7 @@ BFSM_HD void body_gain_fwd(const GainFwdParams<T>& prm, Ctx& ctx) {
             cx<T> v[E];
 #pragma unroll
             for (int m = 0; m < E; ++m)   // [y = u + T m][z = p]
-                v[m] = ctx.template ld_stream_at<N % 64 == 0>(src + (u + TT * m) * N, (unsigned)p * (unsigned)sizeof(cx<T>));
+                v[m] = ctx.template ld_stream_at<Wg<N>::ROW % 64 == 0>(src + (u + TT * m) * N, (unsigned)p * (unsigned)sizeof(cx<T>));
             fft_tile<N, -1, T, (N >= 128)>(v, lds, p, u, twr, ctx);
             const T w = prm.dirw[prm.dir0 + d];
 #pragma unroll
@@ -1316,7 +1344,7 @@ BFSM_HD void body_gain_fwd(const GainFwdParams<T>& prm, Ctx& ctx) {
         auto load_half = [&](cx<T>* t, const cx<T>* src, int h) {
 #pragma unroll
             for (int m = 0; m < H; ++m)
-                t[m] = ctx.template ld_stream_at<N % 64 == 0>(src + (u + TT * (h * H + m)) * N, (unsigned)p * (unsigned)sizeof(cx<T>));
+                t[m] = ctx.template ld_stream_at<Wg<N>::ROW % 64 == 0>(src + (u + TT * (h * H + m)) * N, (unsigned)p * (unsigned)sizeof(cx<T>));
         };
         auto add_half = [&](const cx<T>* t, T w, int h) {
 #pragma unroll
@@ -1345,7 +1373,7 @@ BFSM_HD void body_gain_fwd(const GainFwdParams<T>& prm, Ctx& ctx) {
             const T w = prm.dirw[prm.dir0 + d];
 #pragma unroll
             for (int m = 0; m < E; ++m) {
-                const cx<T> t = ctx.template ld_stream_at<N % 64 == 0>(src + (u + TT * m) * N, (unsigned)p * (unsigned)sizeof(cx<T>));
+                const cx<T> t = ctx.template ld_stream_at<Wg<N>::ROW % 64 == 0>(src + (u + TT * m) * N, (unsigned)p * (unsigned)sizeof(cx<T>));
                 acc[m].x += w * t.x;
                 acc[m].y += w * t.y;
             }
@@ -1392,7 +1420,8 @@ BFSM_HD void body_reduce(const ReduceParams<T>& prm, Ctx& ctx) {
 template <int N, typename T, class Ctx>
 BFSM_HD void body_tail_inv(const TailInvParams<T>& prm, Ctx& ctx) {
     constexpr int E = Wg<N>::E, TT = Wg<N>::T;
-    const int tid = ctx.tid(), p = tid % N, u = ctx.uniform(tid / N, N);
+    int p, u;
+    lane_coords<N, Wg<N>::ROW>(ctx, p, u);
     const int lxi = ctx.bx();
     const bool loss = ctx.by() != 0;
     cx<T>* lds = ctx.template lds<cx<T>>();
@@ -1448,7 +1477,8 @@ template <int N, typename T, class Ctx>
 BFSM_HD void body_tail_line(const TailLineParams<T>& prm, Ctx& ctx) {
     constexpr int E = Wg<N>::E, TT = Wg<N>::T;
     constexpr int NPL = Wg<N>::NPL;
-    const int tid = ctx.tid(), p = tid % NPL, u = ctx.uniform(tid / NPL, NPL);   // p: column inside this block of NPL
+    int p, u;                                   // p: column inside this block of NPL
+    lane_coords<NPL, Wg<N>::LROW>(ctx, p, u);
     const size_t base = (size_t)ctx.by() * N * N * N + (size_t)ctx.bx() * NPL + p;
     cx<T>* lds = ctx.template lds<cx<T>>();
     Twiddles<N, T> twr;
