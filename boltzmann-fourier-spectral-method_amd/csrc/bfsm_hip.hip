@@ -28,7 +28,12 @@ struct DevCtx {
     __device__ __forceinline__ int bz() const { return (int)blockIdx.z; }
     __device__ __forceinline__ int gx() const { return (int)gridDim.x; }
     __device__ __forceinline__ int gy() const { return (int)gridDim.y; }
-    __device__ __forceinline__ void sync() const { __syncthreads(); }
+    __device__ __forceinline__ void sync() const {
+#ifdef BFSM_KO_SYNC     // knock-out builds (tools only): timing experiments, wrong results
+        return;
+#endif
+        __syncthreads();
+    }
     // nothing is scheduled across this point (bounds how many loads the compiler keeps in flight, i.e. registers)
     __device__ __forceinline__ void sched_fence() const { __builtin_amdgcn_sched_barrier(0); }
     // keeps a loaded value (and therefore its load) alive up to this point without using it
