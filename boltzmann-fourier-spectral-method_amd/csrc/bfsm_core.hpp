@@ -721,14 +721,18 @@ BFSM_HD void body_line(const LineParams<T>& prm, Ctx& ctx) {
 // to two tiles' worth of transform data (the split-exchange geometry, and E = 24 points per thread in double precision).
 template <int N, typename T> constexpr bool keep_plane() { return !split_tile<N, T>() && Wg<N>::E * sizeof(cx<T>) <= 256; }
 
-// KA processes the two signs of a direction as a software-pipelined pair of tiles where the geometry leaves one
-// workgroup per CU and the exchange buffer holds complex elements (N = 128 in single precision).
-// BFSM_NO_PIPELINED_PAIR restores the one-tile-after-the-other form (A/B measurements).
+// KA processes the two signs of a direction as a software-pipelined pair of tiles at N = 128 in single precision (one
+// workgroup per CU: nothing else overlaps its exchanges) and at N = 64 in double precision (two workgroups per CU, and
+// still 7 % faster: 12 barriers per direction instead of 14, every burst of LDS stores under the other tile's
+// butterflies; 114 VGPRs.  In single precision at N = 64, where four and more workgroups share a CU, it is 7 % slower).  BFSM_NO_PIPELINED_PAIR restores the one-tile-after-the-other form everywhere,
+// BFSM_NO_PIPELINED_PAIR_64 at N = 64 only (A/B measurements).
 template <int N, typename T> constexpr bool pipelined_pair() {
 #ifdef BFSM_NO_PIPELINED_PAIR
     return false;
-#else
+#elif defined(BFSM_NO_PIPELINED_PAIR_64)
     return N >= 128 && !split_tile<N, T>();
+#else
+    return (N >= 128 && !split_tile<N, T>()) || (N == 64 && sizeof(T) == 8);
 #endif
 }
 
