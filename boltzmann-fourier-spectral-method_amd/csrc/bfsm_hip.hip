@@ -219,6 +219,7 @@ template <K kind, int N, typename T>
 constexpr size_t kernel_lds_bytes() {
     if (kind == K::GainInv && pair_tile<N>()) return pair_lds_bytes<N, T>();
     if (kind == K::GainFwd) return kc_lds_bytes<N, T>();
+    if (kind == K::GainLineAccH) return acch_lds_bytes<N, T>();
     return kind == K::Reduce ? 0 : (is_line_kind(kind) ? line_lds_bytes<N, T>() : tile_lds_bytes<N, T>());
 }
 
@@ -227,6 +228,7 @@ constexpr size_t kernel_lds_bytes() {
 template <K kind, int N, typename T>
 constexpr int kernel_min_waves() {
     if (kind == K::Reduce) return 1;
+    if (kind == K::GainLineAccH && acch_prefetch<N, T>() && BFSM_ACCH_PREFETCH == 1) return 2;   // one 512-thread workgroup per CU, <= 256 VGPRs
     if (N == 64) return sizeof(T) == 4 ? BFSM_F32_N64_WAVES : 4;   // fp32 tiles are 33 KiB: more workgroups fit
     if (N == 32) return 4;                                         // 128-thread workgroups: 8 per CU at <= 128 VGPRs
     if (N == 128 && is_line_kind(kind)) return sizeof(T) == 4 ? 4 : 2;   // fp64: 133 KiB of columns, one workgroup per CU

@@ -181,6 +181,7 @@ struct EmuBackend {
                             : (bfsm::is_line_kind(kind) ? bfsm::Wg<N>::LINE_THREADS : bfsm::Wg<N>::THREADS);
         smem.assign(pair ? bfsm::pair_lds_bytes<N, T>()
                          : kind == bfsm::K::GainFwd ? bfsm::kc_lds_bytes<N, T>()
+                         : kind == bfsm::K::GainLineAccH ? bfsm::acch_lds_bytes<N, T>()
                          : (bfsm::is_line_kind(kind) ? bfsm::line_lds_bytes<N, T>() : bfsm::tile_lds_bytes<N, T>()), 0xCD);
         P copy = prm;
         for (int bz = 0; bz < gz; ++bz)

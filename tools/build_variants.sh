@@ -6,7 +6,7 @@ P=$R/boltzmann-fourier-spectral-method_amd
 mkdir -p $R/gpurun_variants
 for v in "$@"; do
   n=${v%%:*}; f=${v#*:}
-  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wno-unused-function $f -shared -o $R/gpurun_variants/libbfsm_$n.so $P/csrc/bfsm_hip.hip &
+  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wno-unused-function -fno-slp-vectorize $f -shared -o $R/gpurun_variants/libbfsm_$n.so $P/csrc/bfsm_hip.hip &
 done
 wait
 ls -la $R/gpurun_variants

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Per-dispatch durations of the gain kernels from a rocprofv3 kernel trace, split by what preceded the dispatch.
 
-usage: launch_gaps.py <dir with *kernel_trace.csv>
+usage: launch_gaps.py <dir with *kernel_trace.csv> [--transitions]
+  --transitions : additionally the idle time between consecutive dispatches (end of one -> start of the next), per pair
+                  of kernels, for gaps below 100 us (i.e. inside and between queued evaluations)
 Answers "why does KA have a slow tail in the --stats summary of a bench session".  Three populations per kernel:
   after idle : the evaluation it belongs to started within 25 ms after the GPU had been idle for >= 10 ms (a new handle
                being created, the CPU baseline running, process start): the first ~6 evaluations after such a pause run
@@ -51,3 +53,24 @@ for k in sorted(out):
             continue
         sd = statistics.pstdev(v) if len(v) > 1 else 0.0
         print(f"{k:14s} {c:10s} n={len(v):4d} mean={statistics.mean(v):9.1f} min={min(v):9.1f} max={max(v):9.1f} sd={sd:7.1f}")
+
+if "--transitions" in sys.argv:
+    NAMES = {"0": "F1a", "1": "F1b", "5": "KA", "6": "KB", "7": "KC", "8": "reduce", "9": "tail_inv", "10": "tail_line",
+             "11": "KB'", "12": "KN", "13": "KB'H"}
+
+    def short(name):
+        m = re.search(r"\(bfsm::(S?K)\)(\d+),", name)
+        if not m:
+            return name[:24]
+        return ("S" + m.group(2)) if m.group(1) == "SK" else NAMES.get(m.group(2), "K" + m.group(2))
+    tr = {}
+    pe, pn = None, None
+    for s_, e_, name in rows:
+        if pe is not None and 0 <= (s_ - pe) < 100e3:
+            tr.setdefault((short(pn), short(name)), []).append((s_ - pe) / 1e3)
+        pe, pn = e_, name
+    print("idle time between consecutive dispatches in us (pairs with >= 20 samples)")
+    for k in sorted(tr, key=lambda k: -len(tr[k])):
+        v = tr[k]
+        if len(v) >= 20:
+            print(f"{k[0]:>10s} -> {k[1]:<10s} n={len(v):5d} mean={statistics.mean(v):7.2f} median={statistics.median(v):7.2f} max={max(v):7.1f}")
