@@ -736,6 +736,19 @@ template <int N, typename T> constexpr bool pipelined_pair() {
 #endif
 }
 
+// The pipelined pair at N = 128 fp32 exchanges through two planes of floats (real parts, imaginary parts) written and read
+// with the M0-relative LDS forms (Ctx::lds_st8_tid / lds_ld8_tid): a row of lanes is two whole waves, every exchange
+// row is lane-contiguous, so no address register is needed and a store moves two dwords instead of three.  The transposing
+// read, whose addresses are per lane, stays an ordinary (b32) LDS load from the same planes.  BFSM_NO_TID_EXCHANGE: the
+// interleaved-complex exchange (A/B builds).
+template <int N, typename T> constexpr bool tid_exchange() {
+#ifndef BFSM_TID_EXCHANGE          // measured: no gain in the kernel (profiles/r03_ka_tid_exchange_ab.txt); off
+    return false;
+#else
+    return pipelined_pair<N, T>() && N == 128 && sizeof(T) == 4 && Wg<N>::T == 8 && Wg<N>::Q == 2;
+#endif
+}
+
 // KA.  grid = (N planes lx, groups).  For each direction of the group and both signs: phase multiply
 // (compute_alpha_times_f_hat, BoltzmannCUDAKernels.cu:21-59, with the sincos hoisted into separable tables)
 // fused with the (lz,ly) -> (y,z) part of the two batched inverse transforms (CUDABoltzmannOperator.cu:156-164).
@@ -777,23 +790,60 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
         // signs (the two tiles are live together here anyway).  Measured against the sequential form: see DESIGN.md 7.1.
         constexpr int Q = Wg<N>::Q, LS = Wg<N>::LS;
         unsigned pl = (unsigned)p * (unsigned)sizeof(cx<T>);   // this lane's byte offset inside a row
-        auto xw_line = [&](const cx<T>* v) {
+        constexpr bool TIDX = tid_exchange<N, T>();
+        constexpr unsigned PLANE = (unsigned)(N * LS * sizeof(T));           // bytes of one plane of scalars
+        constexpr int RS = LS * (int)sizeof(T);                               // bytes of one row of a plane
+        // wave-uniform byte offsets: row u (stores) / row u * T (line reads) of the real plane + this wave's half of the row
+        const unsigned half = (unsigned)ctx.uniform((tid >> 6) & 1, 64) * 256u;
+        const unsigned wbase = (unsigned)u * (unsigned)RS + half, rbase = (unsigned)(u * TT) * (unsigned)RS + half;
+        T* lre = reinterpret_cast<T*>(lds);
+        T* lim = lre + N * LS;
+        auto xw_line = [&](const cx<T>* v) {       // rows k1 * T + u  (the same rows as xw_tr: u + T * m)
+            if constexpr (TIDX) {
+                ctx.template lds_st8_tid<TT * RS>(wbase, v[0].x, v[1].x, v[2].x, v[3].x, v[4].x, v[5].x, v[6].x, v[7].x);
+                ctx.template lds_st8_tid<TT * RS>(wbase + PLANE, v[0].y, v[1].y, v[2].y, v[3].y, v[4].y, v[5].y, v[6].y, v[7].y);
+                ctx.template lds_st8_tid<TT * RS>(wbase + 8 * TT * RS, v[8].x, v[9].x, v[10].x, v[11].x, v[12].x, v[13].x, v[14].x, v[15].x);
+                ctx.template lds_st8_tid<TT * RS>(wbase + 8 * TT * RS + PLANE, v[8].y, v[9].y, v[10].y, v[11].y, v[12].y, v[13].y, v[14].y, v[15].y);
+            } else {
 #pragma unroll
-            for (int k1 = 0; k1 < E; ++k1) ctx.lds_st(lds + (k1 * TT + u) * LS + p, v[k1]);
+                for (int k1 = 0; k1 < E; ++k1) ctx.lds_st(lds + (k1 * TT + u) * LS + p, v[k1]);
+            }
         };
-        auto xr_line = [&](cx<T>* w2) {
+        auto xr_line = [&](cx<T>* w2) {            // rows (u + T q) * T + uu = u * T + uu + T * T * q
+            if constexpr (TIDX) {
+                float re[16], im[16];
+                ctx.template lds_ld8_tid<RS>(rbase, re);
+                ctx.template lds_ld8_tid<RS>(rbase + PLANE, im);
+                ctx.template lds_ld8_tid<RS>(rbase + TT * TT * RS, re + 8);
+                ctx.template lds_ld8_tid<RS>(rbase + TT * TT * RS + PLANE, im + 8);
+                ctx.lds_tid_wait8(re); ctx.lds_tid_wait8(im); ctx.lds_tid_wait8(re + 8); ctx.lds_tid_wait8(im + 8);
 #pragma unroll
-            for (int q = 0; q < Q; ++q)
+                for (int k = 0; k < 16; ++k) w2[k] = {(T)re[k], (T)im[k]};
+            } else {
 #pragma unroll
-                for (int uu = 0; uu < TT; ++uu) w2[q * TT + uu] = ctx.lds_ld(lds + ((u + TT * q) * TT + uu) * LS + p);
+                for (int q = 0; q < Q; ++q)
+#pragma unroll
+                    for (int uu = 0; uu < TT; ++uu) w2[q * TT + uu] = ctx.lds_ld(lds + ((u + TT * q) * TT + uu) * LS + p);
+            }
         };
         auto xw_tr = [&](const cx<T>* v) {
+            if constexpr (TIDX) xw_line(v);
+            else {
 #pragma unroll
-            for (int m = 0; m < E; ++m) ctx.lds_st(lds + (u + TT * m) * LS + p, v[m]);
+                for (int m = 0; m < E; ++m) ctx.lds_st(lds + (u + TT * m) * LS + p, v[m]);
+            }
         };
         auto xr_tr = [&](cx<T>* v) {
 #pragma unroll
-            for (int m = 0; m < E; ++m) v[m] = ctx.lds_ld(lds + p * LS + (u + TT * m));
+            for (int m = 0; m < E; ++m) {
+                if constexpr (TIDX) v[m] = {ctx.lds_ld_s(lre + p * LS + (u + TT * m)), ctx.lds_ld_s(lim + p * LS + (u + TT * m))};
+                else v[m] = ctx.lds_ld(lds + p * LS + (u + TT * m));
+            }
+        };
+        // barrier that publishes the stores issued before it
+        auto xsync = [&]() {
+            if constexpr (TIDX) ctx.lds_tid_drain();
+            ctx.sync();
         };
         // last step of a tile: the rows of every radix-T sub-transform are stored as soon as it is done, so the stores of
         // the first sub-transform(s) leave under the arithmetic of the following one instead of in one burst of E
@@ -852,27 +902,27 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
                 for (int m = 0; m < E; ++m) vb[m] = cmulc(fh[m], cmul(c0s, ctx.ldc(prm.phz + b * N + u + TT * m)));
             }
             SmallDft<E, +1, T>::run(vb);
-            ctx.sync(); xr_line(wa); ctx.sync();
+            xsync(); xr_line(wa); ctx.sync();
             xw_line(vb);
             ctx.sched_fence();
             fft_line_step2<N, +1, T>(va, wa, twr, ctx);
-            ctx.sync(); xr_line(wb); ctx.sync();
+            xsync(); xr_line(wb); ctx.sync();
             xw_tr(va);
             ctx.sched_fence();
             fft_line_step2<N, +1, T>(vb, wb, twr, ctx);
-            ctx.sync(); xr_tr(va); ctx.sync();
+            xsync(); xr_tr(va); ctx.sync();
             xw_tr(vb);
             ctx.sched_fence();
             SmallDft<E, +1, T>::run(va);
-            ctx.sync(); xr_tr(vb); ctx.sync();
+            xsync(); xr_tr(vb); ctx.sync();
             xw_line(va);
             ctx.sched_fence();
             SmallDft<E, +1, T>::run(vb);
-            ctx.sync(); xr_line(wa); ctx.sync();
+            xsync(); xr_line(wa); ctx.sync();
             xw_line(vb);
             ctx.sched_fence();
             step2_store(prm.a1, d, wa);
-            ctx.sync(); xr_line(wb);
+            xsync(); xr_line(wb);
             ctx.sched_fence();
             step2_store(prm.a2, d, wb);
             if (warming) ctx.keep_alive(warm);
@@ -1242,23 +1292,10 @@ BFSM_HD void hermitian_line_fix(cx<T>* v, const cx<T>* R, int y, int z0, int p, 
     }
 }
 
-// KB' in the Hermitian mode is a chain of latencies per direction (stored rows from HBM -> LDS mirror -> Nyquist terms
-// from L2 -> two transforms), of which two workgroups per CU hide too little (measured: 4.2 - 4.4 TB/s at N = 64, 3.2 at
-// N = 128 fp32).  Where the registers of ONE workgroup per CU (<= 256 VGPRs) hold it, the kernel therefore fetches the
-// NEXT direction's stored rows and Nyquist terms before it works on the current one, keeps the staging rows and the
-// exchange buffer in separate LDS regions (5 barriers per direction), and sends the two lines of a direction through the
-// exchange buffer as a software-pipelined pair (as KA does with its two tiles).  0: the round-2 form (A/B builds).
-#ifndef BFSM_ACCH_PREFETCH
-#define BFSM_ACCH_PREFETCH 0
-#endif
-template <int N, typename T> constexpr bool acch_prefetch() {
-    return BFSM_ACCH_PREFETCH != 0 && N >= 64 && Wg<N>::LROW % 64 == 0 && Wg<N>::E * sizeof(cx<T>) <= 128;
-}
-template <int N, typename T> constexpr size_t acch_lds_bytes() {
-    return acch_prefetch<N, T>() && BFSM_ACCH_PREFETCH == 1 ? (size_t)(2 * (N / 2 + 1) + N) * (Wg<N>::NPL + 1) * sizeof(cx<T>)
-                                                           : line_lds_bytes<N, T>();
-}
-
+// (Measured and rejected, profiles/r03_acch_restructure_ab.txt, code in commit 2cbc66e: fetching the next direction's rows ahead
+// at one workgroup per CU -- 0.55 against 0.42 ms at config 3 -- and sending the two lines of a direction through the
+// exchange buffer as a pipelined pair at two workgroups per CU -- a tie.  One workgroup needs 2.9 us of LDS stores, butterflies
+// and barriers per direction with every global latency hidden; two workgroups overlap that 1.35 x.)
 // KB' (Hermitian mode).  Same as body_gain_line_acc, but the x-lines are rebuilt from the stored half.
 template <int N, typename T, class Ctx>
 BFSM_HD void body_gain_line_acc_h(const GainLineAccHParams<T>& prm, Ctx& ctx) {
@@ -1268,120 +1305,6 @@ BFSM_HD void body_gain_line_acc_h(const GainLineAccHParams<T>& prm, Ctx& ctx) {
     cx<T>* lds = ctx.template lds<cx<T>>();
     Twiddles<N, T> twr;
     twr.load(prm.tw, u, ctx);
-    if constexpr (acch_prefetch<N, T>()) {
-        constexpr int MS = E / 2, H = N / 2, LS = NPL + 1, Q = Wg<N>::Q, NR = E - MS;
-        int gbx, gby;
-        xcd_rows(ctx, gbx, gby);
-        const Segment seg = prm.segs[prm.seg0 + gby];
-        constexpr int BPR = N / NPL;
-        const int y = gbx / BPR, z0 = (gbx % BPR) * NPL;
-        const int colrow = y * N + z0, z = z0 + p;
-        const unsigned pl = (unsigned)p * (unsigned)sizeof(cx<T>);
-        cx<T>* ha = lds;                            // staging rows of A1' (stored half), of A2', then the exchange buffer
-        cx<T>* hb = lds + (H + 1) * LS;
-        constexpr bool AHEAD = BFSM_ACCH_PREFETCH == 1;     // 2: same schedule inside a direction, nothing fetched ahead,
-        cx<T>* xb = AHEAD ? lds + 2 * (H + 1) * LS : lds;   //    one LDS region (two workgroups per CU, <= 128 VGPRs)
-        const T sy = (y & 1) ? (T)-1 : (T)1, sz = (z & 1) ? (T)-1 : (T)1;
-        cx<T> acc[E], na[MS + 1], nb[MS + 1], ra[NR], rb[NR];
-#pragma unroll
-        for (int m = 0; m < E; ++m) acc[m] = {(T)0, (T)0};
-        na[MS] = nb[MS] = {(T)0, (T)0};
-        // stored rows u + T m (m < E/2; the Nyquist plane for u == 0) of both arrays and the per-lane Nyquist terms of the
-        // mirrored rows: everything of direction d that comes from global memory except wave-uniform scalars
-        auto fetch = [&](int d) {
-            const size_t abase = (size_t)ctx.bz() * prm.a_bstride + (size_t)d * NH * N * N;
-            const cx<T>* R = prm.r + (size_t)ctx.bz() * prm.r_bstride + (size_t)d * 4 * NQ * N;
-#pragma unroll
-            for (int m = 0; m < MS; ++m) {
-                na[m] = ctx.template ld_stream_at<true>(prm.a1 + abase + (size_t)(u + TT * m) * N * N + colrow, pl);
-                nb[m] = ctx.template ld_stream_at<true>(prm.a2 + abase + (size_t)(u + TT * m) * N * N + colrow, pl);
-            }
-            if (u == 0) {
-                na[MS] = ctx.template ld_stream_at<true>(prm.a1 + abase + (size_t)H * N * N + colrow, pl);
-                nb[MS] = ctx.template ld_stream_at<true>(prm.a2 + abase + (size_t)H * N * N + colrow, pl);
-            }
-#pragma unroll
-            for (int m = MS; m < E; ++m) {
-                if (m > MS || u != 0) {
-                    const int j = u + TT * m - (H + 1);
-                    ra[m - MS] = R[(size_t)j * N + z];
-                    rb[m - MS] = R[(size_t)(2 * NQ + j) * N + z];
-                } else {
-                    ra[m - MS] = rb[m - MS] = {(T)0, (T)0};
-                }
-            }
-        };
-        // mirrored rows: conj of the stored row N - idx of the same column + the exact Nyquist terms (hermitian_line_fix)
-        auto mirror = [&](cx<T>* v, const cx<T>* hv, const cx<T>* r1v, const cx<T>* R2) {
-#pragma unroll
-            for (int m = MS; m < E; ++m) {
-                if (m > MS || u != 0) {
-                    const int j = u + TT * m - (H + 1);
-                    const cx<T> s = ctx.lds_ld(hv + (N - (u + TT * m)) * LS + p);
-                    const cx<T> r1 = r1v[m - MS];
-                    const cx<T> r2 = ctx.ldc(R2 + (size_t)(NQ + j) * N + y);
-                    v[m] = {s.x + (sy * r1.x + sz * r2.x), -s.y + (sy * r1.y + sz * r2.y)};
-                }
-            }
-        };
-        const int d_end = seg.d0 + seg.n;
-        if (AHEAD && seg.n > 0) fetch(seg.d0);
-        for (int d = seg.d0; d < d_end; ++d) {
-            if constexpr (!AHEAD) fetch(d);
-            const cx<T>* R = prm.r + (size_t)ctx.bz() * prm.r_bstride + (size_t)d * 4 * NQ * N;
-            cx<T> a[E], b[E], r1a[NR], r1b[NR], wa[E], wb[E];
-#pragma unroll
-            for (int m = 0; m <= MS; ++m) { a[m] = na[m]; b[m] = nb[m]; }
-#pragma unroll
-            for (int m = 0; m < NR; ++m) { r1a[m] = ra[m]; r1b[m] = rb[m]; }
-            if (AHEAD && d + 1 < d_end) fetch(d + 1);       // in flight under this direction's transforms
-            ctx.sync();                            // the previous direction's mirror and exchange reads are done
-#pragma unroll
-            for (int m = 0; m < MS; ++m) {
-                ctx.lds_st(ha + (u + TT * m) * LS + p, a[m]);
-                ctx.lds_st(hb + (u + TT * m) * LS + p, b[m]);
-            }
-            ctx.sync();
-            mirror(a, ha, r1a, R);
-            if constexpr (!AHEAD) { mirror(b, hb, r1b, R + (size_t)2 * NQ * N); }
-            SmallDft<E, +1, T>::run(a);
-            if constexpr (!AHEAD) ctx.sync();      // the exchange buffer lies over the staging rows
-#pragma unroll
-            for (int k1 = 0; k1 < E; ++k1) ctx.lds_st(xb + (k1 * TT + u) * LS + p, a[k1]);
-            ctx.sched_fence();
-            if constexpr (AHEAD) { mirror(b, hb, r1b, R + (size_t)2 * NQ * N); }
-            SmallDft<E, +1, T>::run(b);
-            ctx.sync();
-#pragma unroll
-            for (int q = 0; q < Q; ++q)
-#pragma unroll
-                for (int uu = 0; uu < TT; ++uu) wa[q * TT + uu] = ctx.lds_ld(xb + ((u + TT * q) * TT + uu) * LS + p);
-            ctx.sync();
-#pragma unroll
-            for (int k1 = 0; k1 < E; ++k1) ctx.lds_st(xb + (k1 * TT + u) * LS + p, b[k1]);
-            ctx.sched_fence();
-            fft_line_step2<N, +1, T>(a, wa, twr, ctx);
-            ctx.sync();
-#pragma unroll
-            for (int q = 0; q < Q; ++q)
-#pragma unroll
-                for (int uu = 0; uu < TT; ++uu) wb[q * TT + uu] = ctx.lds_ld(xb + ((u + TT * q) * TT + uu) * LS + p);
-            fft_line_step2<N, +1, T>(b, wb, twr, ctx);
-            const T w = prm.dirw[prm.dir0 + d];
-#pragma unroll
-            for (int m = 0; m < E; ++m) {
-                const cx<T> pr = cmul(a[m], b[m]);
-                acc[m].x += w * pr.x;
-                acc[m].y += w * pr.y;
-            }
-        }
-        fft_line_np<N, NPL, -1, T>(acc, xb, p, u, twr, ctx);
-        const size_t obase = (size_t)ctx.bz() * prm.pseg_bstride + (size_t)(prm.seg0 + gby) * N * N * N + colrow;
-#pragma unroll
-        for (int m = 0; m < E; ++m)
-            ctx.template st_at<true>(prm.pseg + obase + (size_t)(u + TT * m) * N * N, pl, acc[m]);
-        return;
-    }
     // the workgroups of a segment share the Nyquist rows R of its directions (31 KiB per direction and array at N = 64):
     // keep them on one XCD (measured: 1.20 x -> 1.0x of the stored bytes fetched)
     int gbx, gby;

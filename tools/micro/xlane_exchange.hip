@@ -10,6 +10,9 @@
 //           v_cndmask (bit 3); no LDS traffic, no barrier
 //   mode 2  butterflies only (no exchange: wrong transform, the arithmetic floor)
 //   mode 3  mode 0 without the butterflies          mode 4  mode 1 without the butterflies
+//   mode 5  LDS exchange through two planes of floats with ds_write_addtid_b32 / ds_read_addtid_b32 (M0-relative, no
+//           address VGPR: 2 cycles per stored dword instead of 6 per ds_write_b64; reads 2 x b32 instead of 1 x b64)
+//   mode 6  mode 5 without the butterflies
 // Both exchanges are checked against a host DFT before timing.
 // build: hipcc -O3 -fno-slp-vectorize --offload-arch=gfx950 -I../../boltzmann-fourier-spectral-method_amd/csrc -o xlane_exchange xlane_exchange.hip
 #include <hip/hip_runtime.h>
@@ -67,12 +70,56 @@ __device__ __forceinline__ void xlane_exchange(cx<float>* v, int lane) {
     }
 }
 
+// split-plane exchange (modes 5, 6): real and imaginary parts in two planes of floats, stored and loaded with the
+// M0-relative ds_*_addtid_b32 forms (address = M0 + offset + 4 * lane: no address VGPR; a store then costs 2 cycles per
+// dword instead of 6 per ds_write_b64)
+__device__ __forceinline__ void addtid_store16(unsigned m0, float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7, float v8, float v9, float v10, float v11, float v12, float v13, float v14, float v15) {
+    asm volatile("s_mov_b32 m0, %16\n\ts_nop 0\n\t"
+        "ds_write_addtid_b32 %0 offset:0\n\t"
+        "ds_write_addtid_b32 %1 offset:4128\n\t"
+        "ds_write_addtid_b32 %2 offset:8256\n\t"
+        "ds_write_addtid_b32 %3 offset:12384\n\t"
+        "ds_write_addtid_b32 %4 offset:16512\n\t"
+        "ds_write_addtid_b32 %5 offset:20640\n\t"
+        "ds_write_addtid_b32 %6 offset:24768\n\t"
+        "ds_write_addtid_b32 %7 offset:28896\n\t"
+        "ds_write_addtid_b32 %8 offset:33024\n\t"
+        "ds_write_addtid_b32 %9 offset:37152\n\t"
+        "ds_write_addtid_b32 %10 offset:41280\n\t"
+        "ds_write_addtid_b32 %11 offset:45408\n\t"
+        "ds_write_addtid_b32 %12 offset:49536\n\t"
+        "ds_write_addtid_b32 %13 offset:53664\n\t"
+        "ds_write_addtid_b32 %14 offset:57792\n\t"
+        "ds_write_addtid_b32 %15 offset:61920\n\t"
+        :: "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v7), "v"(v8), "v"(v9), "v"(v10), "v"(v11), "v"(v12), "v"(v13), "v"(v14), "v"(v15), "s"(m0) : "memory");
+}
+__device__ __forceinline__ void addtid_load16(unsigned m0, float* r) {
+    asm volatile("s_mov_b32 m0, %16\n\ts_nop 0\n\t"
+        "ds_read_addtid_b32 %0 offset:0\n\t"
+        "ds_read_addtid_b32 %1 offset:516\n\t"
+        "ds_read_addtid_b32 %2 offset:1032\n\t"
+        "ds_read_addtid_b32 %3 offset:1548\n\t"
+        "ds_read_addtid_b32 %4 offset:2064\n\t"
+        "ds_read_addtid_b32 %5 offset:2580\n\t"
+        "ds_read_addtid_b32 %6 offset:3096\n\t"
+        "ds_read_addtid_b32 %7 offset:3612\n\t"
+        "ds_read_addtid_b32 %8 offset:33024\n\t"
+        "ds_read_addtid_b32 %9 offset:33540\n\t"
+        "ds_read_addtid_b32 %10 offset:34056\n\t"
+        "ds_read_addtid_b32 %11 offset:34572\n\t"
+        "ds_read_addtid_b32 %12 offset:35088\n\t"
+        "ds_read_addtid_b32 %13 offset:35604\n\t"
+        "ds_read_addtid_b32 %14 offset:36120\n\t"
+        "ds_read_addtid_b32 %15 offset:36636\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7]), "=&v"(r[8]), "=&v"(r[9]), "=&v"(r[10]), "=&v"(r[11]), "=&v"(r[12]), "=&v"(r[13]), "=&v"(r[14]), "=&v"(r[15]) : "s"(m0) : "memory");
+}
 template <int MODE>
 __global__ void __launch_bounds__(1024, 1) probe(const cx<float>* tw, const cx<float>* in, cx<float>* out, int iters) {
     extern __shared__ __align__(16) unsigned char smem[];
     cx<float>* lds = reinterpret_cast<cx<float>*>(smem);
     const int tid = threadIdx.x, lane = tid & 63;
-    constexpr bool XL = (MODE == 1 || MODE == 4), DFT = (MODE <= 2);
+    constexpr bool XL = (MODE == 1 || MODE == 4), DFT = (MODE <= 2 || MODE == 5);
     // line id and position inside the line
     const int u = XL ? (lane >> 3) & 7 : __builtin_amdgcn_readfirstlane(tid / N);
     const int p = XL ? (tid >> 6) * 8 + (lane & 7) : tid % N;          // column = line id inside the workgroup
@@ -95,6 +142,21 @@ __global__ void __launch_bounds__(1024, 1) probe(const cx<float>* tw, const cx<f
             for (int q = 0; q < 2; ++q)
 #pragma unroll
                 for (int uu = 0; uu < TT; ++uu) w2[q * TT + uu] = lds[((u + TT * q) * TT + uu) * LS + p];
+        } else if constexpr (MODE == 5 || MODE == 6) {
+            constexpr unsigned PLANE = N * LS * 4;
+            const unsigned half = 64u * ((unsigned)(tid >> 6) & 1u);
+            const unsigned wb = __builtin_amdgcn_readfirstlane(((unsigned)u * LS + half) * 4u);
+            const unsigned rb = __builtin_amdgcn_readfirstlane(((unsigned)u * TT * LS + half) * 4u);
+            __syncthreads();
+            addtid_store16(wb, v[0].x, v[1].x, v[2].x, v[3].x, v[4].x, v[5].x, v[6].x, v[7].x, v[8].x, v[9].x, v[10].x, v[11].x, v[12].x, v[13].x, v[14].x, v[15].x);
+            addtid_store16(wb + PLANE, v[0].y, v[1].y, v[2].y, v[3].y, v[4].y, v[5].y, v[6].y, v[7].y, v[8].y, v[9].y, v[10].y, v[11].y, v[12].y, v[13].y, v[14].y, v[15].y);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+            float re[16], im[16];
+            addtid_load16(rb, re);
+            addtid_load16(rb + PLANE, im);
+#pragma unroll
+            for (int k = 0; k < E; ++k) w2[k] = {re[k], im[k]};
         } else if constexpr (XL) {
             xlane_exchange(v, lane);
 #pragma unroll
@@ -148,8 +210,8 @@ int main(int argc, char** argv) {
     CHECK(hipMemcpy(d_in, in.data(), in.size() * sizeof(cx<float>), hipMemcpyHostToDevice));
     // correctness of both exchanges: one transform of every line of block 0 against a host DFT
     std::vector<cx<float>> got((size_t)N * N);
-    for (int mode = 0; mode < 2; ++mode) {
-        if (mode == 0) run<0>(d_tw, d_in, d_out, blocks, 1); else run<1>(d_tw, d_in, d_out, blocks, 1);
+    for (int mode : {0, 1, 5}) {
+        if (mode == 0) run<0>(d_tw, d_in, d_out, blocks, 1); else if (mode == 1) run<1>(d_tw, d_in, d_out, blocks, 1); else run<5>(d_tw, d_in, d_out, blocks, 1);
         CHECK(hipMemcpy(got.data(), d_out, got.size() * sizeof(cx<float>), hipMemcpyDeviceToHost));
         double err = 0, ref = 0;
         for (int line = 0; line < N; line += 7)
@@ -163,14 +225,17 @@ int main(int argc, char** argv) {
         std::printf("mode %d: max error of one 128-point transform vs host DFT: %.2e (relative to max %.2e)\n", mode, err / ref, ref);
         if (!(err / ref < 1e-5)) { std::printf("WRONG RESULT\n"); return 1; }
     }
-    const char* names[] = {"LDS exchange + butterflies", "cross-lane exchange + butterflies", "butterflies only", "LDS exchange only", "cross-lane exchange only"};
-    double ms[5];
+    const char* names[] = {"LDS exchange + butterflies", "cross-lane exchange + butterflies", "butterflies only", "LDS exchange only", "cross-lane exchange only",
+                           "split-plane addtid exchange + butterflies", "split-plane addtid exchange only"};
+    double ms[7];
     ms[0] = run<0>(d_tw, d_in, d_out, blocks, iters);
     ms[1] = run<1>(d_tw, d_in, d_out, blocks, iters);
     ms[2] = run<2>(d_tw, d_in, d_out, blocks, iters);
     ms[3] = run<3>(d_tw, d_in, d_out, blocks, iters);
     ms[4] = run<4>(d_tw, d_in, d_out, blocks, iters);
-    for (int m = 0; m < 5; ++m)
+    ms[5] = run<5>(d_tw, d_in, d_out, blocks, iters);
+    ms[6] = run<6>(d_tw, d_in, d_out, blocks, iters);
+    for (int m = 0; m < 7; ++m)
         std::printf("mode %d  %-36s %8.3f ms  = %7.1f ns per line transform of a 1024-thread workgroup (%d workgroups, %d iterations)\n",
                     m, names[m], ms[m], ms[m] * 1e6 / iters / ((blocks + 255) / 256), blocks, iters);
     return 0;
