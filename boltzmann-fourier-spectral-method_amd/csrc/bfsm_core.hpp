@@ -736,19 +736,10 @@ template <int N, typename T> constexpr bool pipelined_pair() {
 #endif
 }
 
-// The pipelined pair at N = 128 fp32 exchanges through two planes of floats (real parts, imaginary parts) written and read
-// with the M0-relative LDS forms (Ctx::lds_st8_tid / lds_ld8_tid): a row of lanes is two whole waves, every exchange
-// row is lane-contiguous, so no address register is needed and a store moves two dwords instead of three.  The transposing
-// read, whose addresses are per lane, stays an ordinary (b32) LDS load from the same planes.  BFSM_NO_TID_EXCHANGE: the
-// interleaved-complex exchange (A/B builds).
-template <int N, typename T> constexpr bool tid_exchange() {
-#ifndef BFSM_TID_EXCHANGE          // measured: no gain in the kernel (profiles/r03_ka_tid_exchange_ab.txt); off
-    return false;
-#else
-    return pipelined_pair<N, T>() && N == 128 && sizeof(T) == 4 && Wg<N>::T == 8 && Wg<N>::Q == 2;
-#endif
-}
-
+// (Measured and rejected for the pipelined pair at N = 128 fp32, profiles/r03_ka_tid_exchange_ab.txt, code in commit 1b825c9:
+// exchanging through two planes of floats with the M0-relative LDS forms ds_write_addtid_b32 / ds_read_addtid_b32 -- no
+// address register, two dwords moved per stored value instead of three.  11 % faster for a line pass in isolation
+// (tools/micro/xlane_exchange.hip, modes 5 / 6), no gain in the kernel: 5.40 - 5.49 against 5.35 - 5.36 ms.)
 // KA.  grid = (N planes lx, groups).  For each direction of the group and both signs: phase multiply
 // (compute_alpha_times_f_hat, BoltzmannCUDAKernels.cu:21-59, with the sincos hoisted into separable tables)
 // fused with the (lz,ly) -> (y,z) part of the two batched inverse transforms (CUDABoltzmannOperator.cu:156-164).
@@ -790,60 +781,23 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
         // signs (the two tiles are live together here anyway).  Measured against the sequential form: see DESIGN.md 7.1.
         constexpr int Q = Wg<N>::Q, LS = Wg<N>::LS;
         unsigned pl = (unsigned)p * (unsigned)sizeof(cx<T>);   // this lane's byte offset inside a row
-        constexpr bool TIDX = tid_exchange<N, T>();
-        constexpr unsigned PLANE = (unsigned)(N * LS * sizeof(T));           // bytes of one plane of scalars
-        constexpr int RS = LS * (int)sizeof(T);                               // bytes of one row of a plane
-        // wave-uniform byte offsets: row u (stores) / row u * T (line reads) of the real plane + this wave's half of the row
-        const unsigned half = (unsigned)ctx.uniform((tid >> 6) & 1, 64) * 256u;
-        const unsigned wbase = (unsigned)u * (unsigned)RS + half, rbase = (unsigned)(u * TT) * (unsigned)RS + half;
-        T* lre = reinterpret_cast<T*>(lds);
-        T* lim = lre + N * LS;
-        auto xw_line = [&](const cx<T>* v) {       // rows k1 * T + u  (the same rows as xw_tr: u + T * m)
-            if constexpr (TIDX) {
-                ctx.template lds_st8_tid<TT * RS>(wbase, v[0].x, v[1].x, v[2].x, v[3].x, v[4].x, v[5].x, v[6].x, v[7].x);
-                ctx.template lds_st8_tid<TT * RS>(wbase + PLANE, v[0].y, v[1].y, v[2].y, v[3].y, v[4].y, v[5].y, v[6].y, v[7].y);
-                ctx.template lds_st8_tid<TT * RS>(wbase + 8 * TT * RS, v[8].x, v[9].x, v[10].x, v[11].x, v[12].x, v[13].x, v[14].x, v[15].x);
-                ctx.template lds_st8_tid<TT * RS>(wbase + 8 * TT * RS + PLANE, v[8].y, v[9].y, v[10].y, v[11].y, v[12].y, v[13].y, v[14].y, v[15].y);
-            } else {
+        auto xw_line = [&](const cx<T>* v) {
 #pragma unroll
-                for (int k1 = 0; k1 < E; ++k1) ctx.lds_st(lds + (k1 * TT + u) * LS + p, v[k1]);
-            }
+            for (int k1 = 0; k1 < E; ++k1) ctx.lds_st(lds + (k1 * TT + u) * LS + p, v[k1]);
         };
-        auto xr_line = [&](cx<T>* w2) {            // rows (u + T q) * T + uu = u * T + uu + T * T * q
-            if constexpr (TIDX) {
-                float re[16], im[16];
-                ctx.template lds_ld8_tid<RS>(rbase, re);
-                ctx.template lds_ld8_tid<RS>(rbase + PLANE, im);
-                ctx.template lds_ld8_tid<RS>(rbase + TT * TT * RS, re + 8);
-                ctx.template lds_ld8_tid<RS>(rbase + TT * TT * RS + PLANE, im + 8);
-                ctx.lds_tid_wait8(re); ctx.lds_tid_wait8(im); ctx.lds_tid_wait8(re + 8); ctx.lds_tid_wait8(im + 8);
+        auto xr_line = [&](cx<T>* w2) {
 #pragma unroll
-                for (int k = 0; k < 16; ++k) w2[k] = {(T)re[k], (T)im[k]};
-            } else {
+            for (int q = 0; q < Q; ++q)
 #pragma unroll
-                for (int q = 0; q < Q; ++q)
-#pragma unroll
-                    for (int uu = 0; uu < TT; ++uu) w2[q * TT + uu] = ctx.lds_ld(lds + ((u + TT * q) * TT + uu) * LS + p);
-            }
+                for (int uu = 0; uu < TT; ++uu) w2[q * TT + uu] = ctx.lds_ld(lds + ((u + TT * q) * TT + uu) * LS + p);
         };
         auto xw_tr = [&](const cx<T>* v) {
-            if constexpr (TIDX) xw_line(v);
-            else {
 #pragma unroll
-                for (int m = 0; m < E; ++m) ctx.lds_st(lds + (u + TT * m) * LS + p, v[m]);
-            }
+            for (int m = 0; m < E; ++m) ctx.lds_st(lds + (u + TT * m) * LS + p, v[m]);
         };
         auto xr_tr = [&](cx<T>* v) {
 #pragma unroll
-            for (int m = 0; m < E; ++m) {
-                if constexpr (TIDX) v[m] = {ctx.lds_ld_s(lre + p * LS + (u + TT * m)), ctx.lds_ld_s(lim + p * LS + (u + TT * m))};
-                else v[m] = ctx.lds_ld(lds + p * LS + (u + TT * m));
-            }
-        };
-        // barrier that publishes the stores issued before it
-        auto xsync = [&]() {
-            if constexpr (TIDX) ctx.lds_tid_drain();
-            ctx.sync();
+            for (int m = 0; m < E; ++m) v[m] = ctx.lds_ld(lds + p * LS + (u + TT * m));
         };
         // last step of a tile: the rows of every radix-T sub-transform are stored as soon as it is done, so the stores of
         // the first sub-transform(s) leave under the arithmetic of the following one instead of in one burst of E
@@ -902,27 +856,27 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
                 for (int m = 0; m < E; ++m) vb[m] = cmulc(fh[m], cmul(c0s, ctx.ldc(prm.phz + b * N + u + TT * m)));
             }
             SmallDft<E, +1, T>::run(vb);
-            xsync(); xr_line(wa); ctx.sync();
+            ctx.sync(); xr_line(wa); ctx.sync();
             xw_line(vb);
             ctx.sched_fence();
             fft_line_step2<N, +1, T>(va, wa, twr, ctx);
-            xsync(); xr_line(wb); ctx.sync();
+            ctx.sync(); xr_line(wb); ctx.sync();
             xw_tr(va);
             ctx.sched_fence();
             fft_line_step2<N, +1, T>(vb, wb, twr, ctx);
-            xsync(); xr_tr(va); ctx.sync();
+            ctx.sync(); xr_tr(va); ctx.sync();
             xw_tr(vb);
             ctx.sched_fence();
             SmallDft<E, +1, T>::run(va);
-            xsync(); xr_tr(vb); ctx.sync();
+            ctx.sync(); xr_tr(vb); ctx.sync();
             xw_line(va);
             ctx.sched_fence();
             SmallDft<E, +1, T>::run(vb);
-            xsync(); xr_line(wa); ctx.sync();
+            ctx.sync(); xr_line(wa); ctx.sync();
             xw_line(vb);
             ctx.sched_fence();
             step2_store(prm.a1, d, wa);
-            xsync(); xr_line(wb);
+            ctx.sync(); xr_line(wb);
             ctx.sched_fence();
             step2_store(prm.a2, d, wb);
             if (warming) ctx.keep_alive(warm);

@@ -38,16 +38,6 @@ struct EmuCtx {
     template <class U> U lds_ld(const U* p) const { return *p; }
     template <class U> void lds_st(U* p, U v) const { *p = v; }
     template <class U> U lds_ld_s(const U* p) const { return *p; }
-    // M0-relative LDS rows (DevCtx::lds_st8_tid / lds_ld8_tid): byte address = base + k * STRIDE + 4 * lane-in-wave
-    template <int STRIDE> void lds_st8_tid(unsigned base, float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7) const {
-        const float v[8] = {v0, v1, v2, v3, v4, v5, v6, v7};
-        for (int k = 0; k < 8; ++k) std::memcpy(smem + base + (unsigned)(k * STRIDE) + 4u * (unsigned)(tid_ % 64), &v[k], 4);
-    }
-    template <int STRIDE> void lds_ld8_tid(unsigned base, float* r) const {
-        for (int k = 0; k < 8; ++k) std::memcpy(&r[k], smem + base + (unsigned)(k * STRIDE) + 4u * (unsigned)(tid_ % 64), 4);
-    }
-    void lds_tid_wait8(float*) const {}
-    void lds_tid_drain() const {}
     template <class U> U ld_stream(const U* p) const { return *p; }
     template <class U> void st_stream(U* p, U v) const { *p = v; }
     template <bool UNI, class U> U ld_stream_at(const U* row, unsigned byte_off) const {
