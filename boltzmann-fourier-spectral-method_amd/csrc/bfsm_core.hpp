@@ -818,6 +818,12 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
 #endif
             }
         };
+#ifdef BFSM_KA_BARRIER_TIMES
+        unsigned long long tbar[13] = {}, t_begin = ctx.clk();
+#define BFSM_TSYNC(k) { const unsigned long long t0_ = ctx.clk(); ctx.sync(); tbar[k] += ctx.clk() - t0_; }
+#else
+#define BFSM_TSYNC(k) ctx.sync();
+#endif
         cx<T> py = {(T)0, (T)0};
         if (d_begin < d_end) py = prm.phy[(size_t)(prm.dir0 + d_begin) * N + p];
         for (int d = d_begin; d < d_end; ++d) {
@@ -847,7 +853,7 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
                 if constexpr (SHARE) vb[m] = cmulc(fh[m], ph);       // conj(alpha1) f_hat / G
             }
             SmallDft<E, +1, T>::run(va);
-            ctx.sync();                         // the previous direction's last exchange has been read
+            BFSM_TSYNC(0);                         // the previous direction's last exchange has been read
             xw_line(va);
             ctx.sched_fence();
             if constexpr (!SHARE) {
@@ -856,31 +862,37 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
                 for (int m = 0; m < E; ++m) vb[m] = cmulc(fh[m], cmul(c0s, ctx.ldc(prm.phz + b * N + u + TT * m)));
             }
             SmallDft<E, +1, T>::run(vb);
-            ctx.sync(); xr_line(wa); ctx.sync();
+            BFSM_TSYNC(1); xr_line(wa); BFSM_TSYNC(2);
             xw_line(vb);
             ctx.sched_fence();
             fft_line_step2<N, +1, T>(va, wa, twr, ctx);
-            ctx.sync(); xr_line(wb); ctx.sync();
+            BFSM_TSYNC(3); xr_line(wb); BFSM_TSYNC(4);
             xw_tr(va);
             ctx.sched_fence();
             fft_line_step2<N, +1, T>(vb, wb, twr, ctx);
-            ctx.sync(); xr_tr(va); ctx.sync();
+            BFSM_TSYNC(5); xr_tr(va); BFSM_TSYNC(6);
             xw_tr(vb);
             ctx.sched_fence();
             SmallDft<E, +1, T>::run(va);
-            ctx.sync(); xr_tr(vb); ctx.sync();
+            BFSM_TSYNC(7); xr_tr(vb); BFSM_TSYNC(8);
             xw_line(va);
             ctx.sched_fence();
             SmallDft<E, +1, T>::run(vb);
-            ctx.sync(); xr_line(wa); ctx.sync();
+            BFSM_TSYNC(9); xr_line(wa); BFSM_TSYNC(10);
             xw_line(vb);
             ctx.sched_fence();
             step2_store(prm.a1, d, wa);
-            ctx.sync(); xr_line(wb);
+            BFSM_TSYNC(11); xr_line(wb);
             ctx.sched_fence();
             step2_store(prm.a2, d, wb);
             if (warming) ctx.keep_alive(warm);
         }
+#ifdef BFSM_KA_BARRIER_TIMES
+#pragma unroll
+        for (int k = 0; k < 13; ++k) ctx.dbg_add(k, tbar[k]);
+        ctx.dbg_add(13, ctx.clk() - t_begin);      // the wave's whole direction loop
+        ctx.dbg_add(14, 1);                        // waves
+#endif
     } else if constexpr (N >= 64 && KEEP) {
         // One iteration = one direction; both signs are produced by the same code with the sign a compile-time flag
         // (e^{+-i theta} / G = (phx[lx] * phy[ly = p]) * phz[lz = u + T m], conjugated for sign 1), so no per-point select

@@ -36,6 +36,10 @@ struct DevCtx {
     }
     // nothing is scheduled across this point (bounds how many loads the compiler keeps in flight, i.e. registers)
     __device__ __forceinline__ void sched_fence() const { __builtin_amdgcn_sched_barrier(0); }
+#ifdef BFSM_KA_BARRIER_TIMES     // instrumented build (tools only): cycles every wave spends inside each barrier of KA's pair loop
+    __device__ __forceinline__ unsigned long long clk() const { return __builtin_readcyclecounter(); }
+    __device__ __forceinline__ void dbg_add(int i, unsigned long long v) const;
+#endif
     // keeps a loaded value (and therefore its load) alive up to this point without using it
     template <class T>
     __device__ __forceinline__ void keep_alive(T v) const { asm volatile("" ::"v"(v)); }
@@ -209,6 +213,21 @@ struct DevCtx {
         return cx<T>{q[0], q[1]};
     }
 };
+
+#ifdef BFSM_KA_BARRIER_TIMES
+__device__ unsigned long long bfsm_dbg_counters[32];
+__device__ __forceinline__ void DevCtx::dbg_add(int i, unsigned long long v) const {
+    if ((threadIdx.x & 63) == 0) atomicAdd(&bfsm_dbg_counters[i], v);
+}
+extern "C" int bfsm_debug_counters(unsigned long long* out32, int reset) {
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(bfsm_dbg_counters), sizeof(unsigned long long) * 32) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[32] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(bfsm_dbg_counters), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
 
 template <K kind, int N>
 constexpr int kernel_threads() {
