@@ -736,159 +736,9 @@ template <int N, typename T> constexpr bool pipelined_pair() {
 #endif
 }
 
-// ---- experiment (BFSM_KA_WIDE32): KA at N = 128 fp32 with 32 points per thread --------------------------------------
-// 512 threads per tile (two waves per SIMD, <= 256 VGPRs), the 2-D tile transform in THREE register passes with TWO
-// exchanges instead of four passes with three:  z: 128 = 32 x 4,  y: 128 = 8 x 16;
-//   pass 1  thread (a, ly):   32-point transform along lz = a + 4 m, twiddle W128^(a k1)
-//   pass 2  thread (k1, b):   4-point transform over a (z = k1 + 32 k2)  x  8-point transform over j (ly = b + 16 j),
-//                             twiddle W128^(b j')
-//   pass 3  thread (j' mod 4, z):  two 16-point transforms over b (y = j' + 8 b'), rows stored with z along the lanes.
-// 8 barriers per direction instead of 12, one third less LDS traffic, half the waves.
-template <int N, typename T> constexpr bool wide_tile() {
-#ifdef BFSM_KA_WIDE32
-    return N == 128 && sizeof(T) == 4;
-#else
-    return false;
-#endif
-}
-constexpr int WIDE_THREADS = 512, WIDE_RS1 = 132, WIDE_RS2 = 130;
-template <typename T> constexpr size_t wide_lds_bytes() { return (size_t)128 * WIDE_RS1 * sizeof(cx<T>); }
-
-BFSM_HD constexpr double cos32(int j) {  // cos(2*pi*j/32)
-    j &= 31;
-    if (j > 16) j = 32 - j;
-    switch (j) {
-        case 0: return 1.0;
-        case 1: return 0.98078528040323044913;
-        case 2: return 0.92387953251128673848;
-        case 3: return 0.83146961230254523708;
-        case 4: return 0.70710678118654752440;
-        case 5: return 0.55557023301960222474;
-        case 6: return 0.38268343236508977173;
-        case 7: return 0.19509032201612826785;
-        case 8: return 0.0;
-        case 9: return -0.19509032201612826785;
-        case 10: return -0.38268343236508977173;
-        case 11: return -0.55557023301960222474;
-        case 12: return -0.70710678118654752440;
-        case 13: return -0.83146961230254523708;
-        case 14: return -0.92387953251128673848;
-        case 15: return -0.98078528040323044913;
-        default: return -1.0;
-    }
-}
-BFSM_HD constexpr double sin32(int j) { return cos32(j + 24); }   // sin(x) = cos(x - pi/2)
-
-// 32 points in registers: two 16-point transforms of the even / odd inputs + 16 butterflies
-template <int SGN, typename T>
-BFSM_HD void dft32(cx<T>* a) {
-#ifdef BFSM_KO_DFT
-    return;
-#endif
-    cx<T> e[16], o[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { e[k] = a[2 * k]; o[k] = a[2 * k + 1]; }
-    SmallDft<16, SGN, T>::run(e);
-    SmallDft<16, SGN, T>::run(o);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        if (k == 0) { a[0] = cadd(e[0], o[0]); a[16] = csub(e[0], o[0]); }
-        else if (k == 8) { const cx<T> t = rot90<SGN>(o[8]); a[8] = cadd(e[8], t); a[24] = csub(e[8], t); }
-        else {
-            cx<T> x = e[k], y = o[k];
-            bfly_tw(x, y, (T)cos32(k), (T)(SGN * sin32(k)));
-            a[k] = x;
-            a[k + 16] = y;
-        }
-    }
-}
-
-template <int N, typename T, class Ctx>
-BFSM_HD void body_gain_inv_wide(const GainInvParams<T>& prm, Ctx& ctx) {
-    static_assert(N == 128, "geometry");
-    constexpr int RS1 = WIDE_RS1, RS2 = WIDE_RS2;
-    const int tid = ctx.tid();
-    const int a = ctx.uniform(tid >> 7, 128), ly = tid & 127;       // pass 1 (and jp = a, z = ly in pass 3)
-    const int k1 = tid >> 4, b = tid & 15;                           // pass 2
-    const int lxi = ctx.bx();
-    cx<T>* lds = ctx.template lds<cx<T>>();
-    const size_t bz = (size_t)ctx.bz();
-    const cx<T>* src = prm.fhat + bz * N * N * N + (size_t)lxi * N * N;
-    cx<T> fh[32];
-#pragma unroll
-    for (int m = 0; m < 32; ++m) fh[m] = src[(a + 4 * m) * N + ly];       // [lz = a + 4 m][ly]
-    cx<T> wy[8];                                                          // W128^(+ b j'), per lane
-    wy[0] = {(T)1, (T)0};
-#pragma unroll
-    for (int j = 1; j < 8; ++j) { const cx<T> t = prm.tw[(b * j) % N]; wy[j] = {t.x, -t.y}; }
-    const int d_begin = ctx.by() * prm.per_group;
-    int d_end = d_begin + prm.per_group;
-    if (d_end > prm.n_dir) d_end = prm.n_dir;
-    cx<T> py = {(T)0, (T)0};
-    if (d_begin < d_end) py = prm.phy[(size_t)(prm.dir0 + d_begin) * N + ly];
-    for (int d = d_begin; d < d_end; ++d) {
-        const size_t bd = (size_t)(prm.dir0 + d);
-        const cx<T> c0 = cmul(ctx.ldc(prm.phx + bd * N + lxi), py);
-        if (d + 1 < d_end) py = prm.phy[(size_t)(prm.dir0 + d + 1) * N + ly];
-        unsigned pl = ctx.lane_off((unsigned)ly * (unsigned)sizeof(cx<T>));
-        auto one_sign = [&](auto conj_tag) {
-            constexpr bool CONJ = decltype(conj_tag)::value;
-            const cx<T> c0s = CONJ ? ctx.opaque_cx(c0) : c0;
-            cx<T> v[32];
-#pragma unroll
-            for (int m = 0; m < 32; ++m) {
-                const cx<T> ph = cmul(c0s, ctx.ldc(prm.phz + bd * N + a + 4 * m));
-                v[m] = CONJ ? cmulc(fh[m], ph) : cmul(fh[m], ph);
-            }
-            dft32<+1, T>(v);
-#pragma unroll
-            for (int k = 1; k < 32; ++k) {                                  // W128^(+ a k): wave-uniform
-                const cx<T> t = ctx.ldc(prm.tw + ((ctx.opaque(a) * k) % N));
-                v[k] = cmulc(v[k], t);                                      // times conj(tw) = exp(+i ...)
-            }
-            ctx.sync();                                                     // the previous tile's last reads are done
-#pragma unroll
-            for (int k = 0; k < 32; ++k) ctx.lds_st(lds + (k * 4 + a) * RS1 + ly, v[k]);
-            ctx.sync();
-            cx<T> u[32];                                                    // u[j * 4 + aa]
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-#pragma unroll
-                for (int aa = 0; aa < 4; ++aa) u[j * 4 + aa] = ctx.lds_ld(lds + (k1 * 4 + aa) * RS1 + b + 16 * j);
-            ctx.sync();
-#pragma unroll
-            for (int j = 0; j < 8; ++j) SmallDft<4, +1, T>::run(u + 4 * j);  // over a: u[j * 4 + k2]
-#pragma unroll
-            for (int k2 = 0; k2 < 4; ++k2) {
-                cx<T> g[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) g[j] = u[j * 4 + k2];
-                SmallDft<8, +1, T>::run(g);                                  // over j: g[j']
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const cx<T> r = (j == 0) ? g[0] : cmul(g[j], wy[j]);
-                    ctx.lds_st(lds + (j * 16 + b) * RS2 + k1 + 32 * k2, r);
-                }
-            }
-            ctx.sync();
-            cx<T>* dst = (CONJ ? prm.a2 : prm.a1) + bz * prm.a_bstride + ((size_t)d * prm.planes + lxi) * N * N;
-#pragma unroll
-            for (int sgl = 0; sgl < 2; ++sgl) {
-                const int jq = a + 4 * sgl;                                  // j' of this set (wave-uniform)
-                cx<T> h[16];
-#pragma unroll
-                for (int bb = 0; bb < 16; ++bb) h[bb] = ctx.lds_ld(lds + (jq * 16 + bb) * RS2 + ly);
-                SmallDft<16, +1, T>::run(h);                                 // over b: h[b'],  y = j' + 8 b'
-#pragma unroll
-                for (int bp = 0; bp < 16; ++bp)
-                    ctx.template st_stream_at<true>(dst + (size_t)(jq + 8 * bp) * N, pl, h[bp]);
-            }
-        };
-        one_sign(BoolTag<false>{});
-        one_sign(BoolTag<true>{});
-    }
-}
-
+// (Measured and rejected at N = 128 fp32, profiles/r03_ka_wide32_ab.txt, code in commit ab65758: 32 points per thread, 512 threads per
+// tile, the 2-D tile transform in three register passes -- z: 32 x 4, y: 8 x 16 -- with two exchanges and 8 barriers per
+// direction instead of three and 12.  Correct, 227 VGPRs, 6.40 against 5.35 ms: half the waves hide less than the exchanges save.)
 // (Measured and rejected for the pipelined pair at N = 128 fp32, profiles/r03_ka_tid_exchange_ab.txt, code in commit 1b825c9:
 // exchanging through two planes of floats with the M0-relative LDS forms ds_write_addtid_b32 / ds_read_addtid_b32 -- no
 // address register, two dwords moved per stored value instead of three.  11 % faster for a line pass in isolation

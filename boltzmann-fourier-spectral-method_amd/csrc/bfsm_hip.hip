@@ -229,15 +229,13 @@ extern "C" int bfsm_debug_counters(unsigned long long* out32, int reset) {
 }
 #endif
 
-template <K kind, int N, typename T = double>
+template <K kind, int N>
 constexpr int kernel_threads() {
-    if (kind == K::GainInv && wide_tile<N, T>()) return WIDE_THREADS;
     if (kind == K::GainInv && pair_tile<N>()) return pair_threads<N>();      // two tiles side by side (N = 32)
     return kind == K::Reduce ? 256 : (is_line_kind(kind) ? Wg<N>::LINE_THREADS : Wg<N>::THREADS);
 }
 template <K kind, int N, typename T>
 constexpr size_t kernel_lds_bytes() {
-    if (kind == K::GainInv && wide_tile<N, T>()) return wide_lds_bytes<T>();
     if (kind == K::GainInv && pair_tile<N>()) return pair_lds_bytes<N, T>();
     if (kind == K::GainFwd) return kc_lds_bytes<N, T>();
     return kind == K::Reduce ? 0 : (is_line_kind(kind) ? line_lds_bytes<N, T>() : tile_lds_bytes<N, T>());
@@ -248,7 +246,6 @@ constexpr size_t kernel_lds_bytes() {
 template <K kind, int N, typename T>
 constexpr int kernel_min_waves() {
     if (kind == K::Reduce) return 1;
-    if (kind == K::GainInv && wide_tile<N, T>()) return 2;
     if (N == 64) return sizeof(T) == 4 ? BFSM_F32_N64_WAVES : 4;   // fp32 tiles are 33 KiB: more workgroups fit
     if (N == 32) return 4;                                         // 128-thread workgroups: 8 per CU at <= 128 VGPRs
     if (N == 128 && is_line_kind(kind)) return sizeof(T) == 4 ? 4 : 2;   // fp64: 133 KiB of columns, one workgroup per CU
@@ -256,7 +253,7 @@ constexpr int kernel_min_waves() {
 }
 
 template <K kind, int N, typename T, class P>
-__global__ void __launch_bounds__((kernel_threads<kind, N, T>()), (kernel_min_waves<kind, N, T>())) bfsm_kernel(const P prm) {
+__global__ void __launch_bounds__((kernel_threads<kind, N>()), (kernel_min_waves<kind, N, T>())) bfsm_kernel(const P prm) {
     extern __shared__ __align__(16) unsigned char bfsm_smem[];
     DevCtx ctx{bfsm_smem};
     if constexpr (kind == K::TileFwdReal) body_tile_fwd_real<N, T>(prm, ctx);
@@ -264,7 +261,6 @@ __global__ void __launch_bounds__((kernel_threads<kind, N, T>()), (kernel_min_wa
     else if constexpr (kind == K::LineInv) body_line<N, +1, T>(prm, ctx);
     else if constexpr (kind == K::TileFwd) body_tile_c2c<N, -1, T>(prm, ctx);
     else if constexpr (kind == K::TileInv) body_tile_c2c<N, +1, T>(prm, ctx);
-    else if constexpr (kind == K::GainInv && wide_tile<N, T>()) body_gain_inv_wide<N, T>(prm, ctx);
     else if constexpr (kind == K::GainInv && pair_tile<N>()) body_gain_inv_pair<N, T>(prm, ctx);
     else if constexpr (kind == K::GainInv) body_gain_inv<N, T>(prm, ctx);
     else if constexpr (kind == K::GainLine) body_gain_line<N, T>(prm, ctx);
@@ -364,7 +360,7 @@ struct HipBackend {
     template <K kind, int N, typename T, class P>
     void launch_n(int gx, int gy, int gz, const P& prm) {
         static std::atomic<unsigned long long> opted{0};
-        launch_any(reinterpret_cast<const void*>(bfsm_kernel<kind, N, T, P>), gx, gy, gz, kernel_threads<kind, N, T>(),
+        launch_any(reinterpret_cast<const void*>(bfsm_kernel<kind, N, T, P>), gx, gy, gz, kernel_threads<kind, N>(),
                    kernel_lds_bytes<kind, N, T>(), &prm, opted);
     }
 

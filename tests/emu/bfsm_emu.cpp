@@ -162,7 +162,6 @@ struct EmuBackend {
         else if constexpr (kind == K::LineInv) body_line<N, +1, T>(prm, ctx);
         else if constexpr (kind == K::TileFwd) body_tile_c2c<N, -1, T>(prm, ctx);
         else if constexpr (kind == K::TileInv) body_tile_c2c<N, +1, T>(prm, ctx);
-        else if constexpr (kind == K::GainInv && wide_tile<N, T>()) body_gain_inv_wide<N, T>(prm, ctx);
         else if constexpr (kind == K::GainInv && pair_tile<N>()) body_gain_inv_pair<N, T>(prm, ctx);
         else if constexpr (kind == K::GainInv) body_gain_inv<N, T>(prm, ctx);
         else if constexpr (kind == K::GainLine) body_gain_line<N, T>(prm, ctx);
@@ -178,10 +177,9 @@ struct EmuBackend {
     template <bfsm::K kind, int N, typename T, class P>
     void launch_n(int gx, int gy, int gz, const P& prm) {
         const bool pair = kind == bfsm::K::GainInv && bfsm::pair_tile<N>();
-        const bool wide = kind == bfsm::K::GainInv && bfsm::wide_tile<N, T>();
-        const int threads = wide ? bfsm::WIDE_THREADS : pair ? bfsm::pair_threads<N>() : kind == bfsm::K::Reduce ? 256
+        const int threads = pair ? bfsm::pair_threads<N>() : kind == bfsm::K::Reduce ? 256
                             : (bfsm::is_line_kind(kind) ? bfsm::Wg<N>::LINE_THREADS : bfsm::Wg<N>::THREADS);
-        smem.assign(wide ? bfsm::wide_lds_bytes<T>() : pair ? bfsm::pair_lds_bytes<N, T>()
+        smem.assign(pair ? bfsm::pair_lds_bytes<N, T>()
                          : kind == bfsm::K::GainFwd ? bfsm::kc_lds_bytes<N, T>()
                          : (bfsm::is_line_kind(kind) ? bfsm::line_lds_bytes<N, T>() : bfsm::tile_lds_bytes<N, T>()), 0xCD);
         P copy = prm;
