@@ -511,6 +511,12 @@ struct GainInvParams {       // KA
     size_t a_bstride;        // elements between consecutive batch members (blockIdx.z) in a1 / a2
     int planes;              // lx planes stored per direction: N, or N/2 + 1 (indices 0..N/2) in the Hermitian mode
     int warm_tables;         // != 0: touch the phase-table rows two iterations ahead (tables larger than an XCD's L2)
+    // Hermitian mode where KN's workgroups have KA's shape (nyq_rides_along): the Nyquist-row transforms of the chunk run
+    // as extra workgroups of this launch -- blockIdx.y >= ka_groups -- instead of as a launch of their own
+    cx<T>* r;                // KN's output (NyqRowsParams::r), or null
+    size_t r_bstride;
+    int kn_blocks;           // KN workgroups appended (0: none)
+    int ka_groups;           // blockIdx.y below this: KA
 };
 
 template <typename T>
@@ -1185,6 +1191,42 @@ BFSM_HD void body_nyq_rows(const NyqRowsParams<T>& prm, Ctx& ctx) {
 #pragma unroll
         for (int m = 0; m < E; ++m) dst[u + TT * m] = v[m];
     }
+}
+
+// KN rides along with KA where its workgroups have KA's thread count and one column block covers its 2 (N/2 - 1) columns
+// (N = 64: 512 threads both; at N = 128 KA has 1024).  Saves the launch and drain of a 30 us kernel per chunk: KN's
+// workgroups take the slots KA's grid leaves free and the slots of KA workgroups that finish early.
+template <int N> constexpr bool nyq_rides_along() {
+#ifdef BFSM_NO_KN_RIDE
+    return false;
+#else
+    return N == 64 && Wg<N>::THREADS == Wg<N>::LINE_THREADS && 2 * (N / 2 - 1) <= Wg<N>::NPL && !pair_tile<N>();
+#endif
+}
+template <int N, typename T> constexpr size_t gain_inv_lds_bytes() {
+    return nyq_rides_along<N>() && line_lds_bytes<N, T>() > tile_lds_bytes<N, T>() ? line_lds_bytes<N, T>() : tile_lds_bytes<N, T>();
+}
+// block indices seen by a body that runs as a guest of another kernel's grid
+template <class Ctx>
+struct GuestCtx : Ctx {
+    int bx_, by_;
+    BFSM_HD GuestCtx(const Ctx& c, int bx, int by) : Ctx(c), bx_(bx), by_(by) {}
+    BFSM_HD int bx() const { return bx_; }
+    BFSM_HD int by() const { return by_; }
+};
+template <int N, typename T, class Ctx>
+BFSM_HD void body_gain_inv_entry(const GainInvParams<T>& prm, Ctx& ctx) {
+    if constexpr (nyq_rides_along<N>()) {
+        if (prm.kn_blocks > 0 && ctx.by() >= prm.ka_groups) {            // workgroup-uniform
+            const int kn = (ctx.by() - prm.ka_groups) * ctx.gx() + ctx.bx();
+            if (kn >= prm.kn_blocks) return;
+            const NyqRowsParams<T> pk{prm.fhat, prm.r, prm.phx, prm.phy, prm.phz, prm.tw, prm.dir0, prm.r_bstride};
+            GuestCtx<Ctx> g(ctx, 0, kn);
+            body_nyq_rows<N, T>(pk, g);
+            return;
+        }
+    }
+    body_gain_inv<N, T>(prm, ctx);
 }
 
 // x-lines of A1', A2' in the Hermitian mode: rows idx = u + T*m of column col = y*N + z.  Only the planes 0 .. N/2 are

@@ -402,6 +402,7 @@ struct Pipeline {
 
     double cbytes() const { return (double)sizeof(cx<T>); }
     int line_blocks() const { return plan.N * (plan.N / line_npl(plan.N)); }   // Wg<N>::NPL columns per workgroup
+    static bool kn_rides_along(int n) { return n == 64 && nyq_rides_along<64>(); }
 
     // f_hat = FFT(f), then the gain term of this shard into qhat (partial Q_gain_hat, spectral layout).
     // nb distributions f_dev[nb][G] are processed by the same launches (grid.z / grid.y = batch member); all
@@ -436,10 +437,14 @@ struct Pipeline {
             // phase tables beyond ~3 MiB do not stay in an XCD's L2 next to the streams: KA touches the rows ahead
             // (N = 64, config 4: 3 x 2.4 MiB of tables, KA 3.88 -> 3.66 ms; N = 128, config 5: 62 -> 52 ms)
             const bool warm = N >= 64 && 3.0 * (double)plan.n_dirs() * N * sizeof(cx<T>) > 3.0 * 1024 * 1024;
-            GainInvParams<T> ka{fhat, a1, a2, phx, phy, phz, tw, c.dir0, c.n, per_group_a, a_bs, a_planes, warm ? 1 : 0};
             const int ga = (c.n + per_group_a - 1) / per_group_a;
+            // Hermitian mode, N = 64: the chunk's 2 c.n Nyquist-row workgroups (KN) ride along as extra rows of KA's grid
+            const bool kn_rides = plan.hermitian && kn_rides_along(N);
+            const int kn_blocks = kn_rides ? 2 * c.n : 0, kn_rows = (kn_blocks + a_planes - 1) / a_planes;
+            GainInvParams<T> ka{fhat, a1, a2, phx, phy, phz, tw, c.dir0, c.n, per_group_a, a_bs, a_planes, warm ? 1 : 0,
+                                kn_rides ? rnyq : nullptr, r_bs, kn_blocks, ga};
             be->mark(BFSM_K_GAIN_INV, 2.0 * c.n * Gc * hfrac);
-            be->template launch<K::GainInv, T>(a_planes, ga, nb, ka, N);
+            be->template launch<K::GainInv, T>(a_planes, ga + kn_rows, nb, ka, N);
             if (!plan.exact_reductions) {
                 GainLineParams<T> kb{a1, a2, tw, a_bs};
                 be->mark(BFSM_K_GAIN_LINE, 3.0 * c.n * Gc);
@@ -452,10 +457,12 @@ struct Pipeline {
                 be->mark(BFSM_K_GAIN_LINE, (2.0 * c.n + c.n_seg) * Gc);
                 be->template launch<K::GainLineAcc, T>(line_blocks(), c.n_seg, nb, kb, N);
             } else {
-                NyqRowsParams<T> kn{fhat, rnyq, phx, phy, phz, tw, c.dir0, r_bs};
-                const int npl = line_npl(N), ncol = 2 * (N / 2 - 1);
-                be->mark(BFSM_K_GAIN_INV, 0.0);
-                be->template launch<K::NyqRows, T>((ncol + npl - 1) / npl, 2 * c.n, nb, kn, N);
+                if (!kn_rides) {
+                    NyqRowsParams<T> kn{fhat, rnyq, phx, phy, phz, tw, c.dir0, r_bs};
+                    const int npl = line_npl(N), ncol = 2 * (N / 2 - 1);
+                    be->mark(BFSM_K_GAIN_INV, 0.0);
+                    be->template launch<K::NyqRows, T>((ncol + npl - 1) / npl, 2 * c.n, nb, kn, N);
+                }
                 GainLineAccHParams<T> kb{a1, a2, rnyq, pseg, dirw, segs, tw, c.dir0, c.seg0, a_bs, s_bs, r_bs};
                 be->mark(BFSM_K_GAIN_LINE, (2.0 * c.n * hfrac + c.n_seg) * Gc);
                 be->template launch<K::GainLineAccH, T>(line_blocks(), c.n_seg, nb, kb, N);
