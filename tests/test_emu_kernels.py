@@ -233,7 +233,8 @@ HERMITIAN = 4   # BFSM_FLAG_HERMITIAN (only together with EXACT)
 
 
 @pytest.mark.parametrize("nv,n_gl,n_sph,max_chunk", [(16, 3, 12, 0), (16, 3, 12, 5), (32, 2, 6, 0), (48, 2, 6, 0),
-                                                     (96, 1, 6, 0), (80, 1, 6, 0), (24, 3, 12, 0), (40, 2, 6, 0)])
+                                                     (96, 1, 6, 0), (80, 1, 6, 0), (24, 3, 12, 0), (40, 2, 6, 0),
+                                                     (64, 2, 6, 0), (64, 3, 12, 4)])   # N = 64: KN rides in KA's grid
 def test_hermitian_reduction_matches_oracle(oracle, nv, n_gl, n_sph, max_chunk):
     """f real => A'[-lx] = conj A'[lx] + exact rank-one Nyquist terms: only the planes lx = 0..N/2 are computed and
     stored.  The perturbed input has energy in all three Nyquist planes, so a wrong correction shows at 1e-3."""
@@ -245,6 +246,21 @@ def test_hermitian_reduction_matches_oracle(oracle, nv, n_gl, n_sph, max_chunk):
     Q, qhat = E.collide(f, gl, sph, GAMMA, B_GAMMA, L, 64, max_chunk=max_chunk, flags=EXACT | HERMITIAN)
     assert np.abs(qhat - qo).max() <= 1e-12 * np.abs(qo).max()
     assert np.abs(Q - Qo).max() <= 1e-12 * np.abs(Qo).max()
+
+
+def test_hermitian_n64_batch_with_guest_workgroups(oracle):
+    """N = 64: the Nyquist-row workgroups are appended to KA's grid (nyq_rides_along); with a batch the grid has a z
+    extent as well and every member must still equal its single evaluation bitwise and the oracle to 1e-12."""
+    f0, _, L, _ = oracle.bkw(64)
+    fs = np.stack([oracle.perturbed_input(f0, seed=s) for s in (3, 4)])
+    gl = oracle.gauss_legendre(2, 0.0, R)
+    sph = oracle.spherical_design(6)
+    Qb = E.collide_batch(fs, gl, sph, GAMMA, B_GAMMA, L, max_chunk=2, flags=EXACT | HERMITIAN)
+    for i in range(2):
+        Qi, _ = E.collide(fs[i], gl, sph, GAMMA, B_GAMMA, L, 64, max_chunk=2, flags=EXACT | HERMITIAN)
+        assert np.array_equal(Qb[i], Qi)
+        Qo = oracle.collide(fs[i], gl, sph, GAMMA, B_GAMMA, L)
+        assert np.abs(Qb[i] - Qo).max() <= 1e-12 * np.abs(Qo).max()
 
 
 def test_hermitian_needs_exact_flag():
