@@ -511,11 +511,16 @@ struct GainInvParams {       // KA
     size_t a_bstride;        // elements between consecutive batch members (blockIdx.z) in a1 / a2
     int planes;              // lx planes stored per direction: N, or N/2 + 1 (indices 0..N/2) in the Hermitian mode
     int warm_tables;         // != 0: touch the phase-table rows two iterations ahead (tables larger than an XCD's L2)
-    // Hermitian mode where KN's workgroups have KA's shape (nyq_rides_along): the Nyquist-row transforms of the chunk run
-    // as extra workgroups of this launch -- blockIdx.y >= ka_groups -- instead of as a launch of their own
-    cx<T>* r;                // KN's output (NyqRowsParams::r), or null
+};
+
+// Hermitian mode where KN's workgroups have KA's shape (nyq_rides_along): the Nyquist-row transforms of the chunk run
+// as extra workgroups of KA's launch -- blockIdx.y >= ka_groups -- instead of as a launch of their own
+template <typename T>
+struct GainInvNyqParams {    // KA + guest KN workgroups
+    GainInvParams<T> ka;
+    cx<T>* r;                // KN's output (NyqRowsParams::r)
     size_t r_bstride;
-    int kn_blocks;           // KN workgroups appended (0: none)
+    int kn_blocks;           // KN workgroups appended
     int ka_groups;           // blockIdx.y below this: KA
 };
 
@@ -1215,18 +1220,16 @@ struct GuestCtx : Ctx {
     BFSM_HD int by() const { return by_; }
 };
 template <int N, typename T, class Ctx>
-BFSM_HD void body_gain_inv_entry(const GainInvParams<T>& prm, Ctx& ctx) {
-    if constexpr (nyq_rides_along<N>()) {
-        if (prm.kn_blocks > 0 && ctx.by() >= prm.ka_groups) {            // workgroup-uniform
-            const int kn = (ctx.by() - prm.ka_groups) * ctx.gx() + ctx.bx();
-            if (kn >= prm.kn_blocks) return;
-            const NyqRowsParams<T> pk{prm.fhat, prm.r, prm.phx, prm.phy, prm.phz, prm.tw, prm.dir0, prm.r_bstride};
-            GuestCtx<Ctx> g(ctx, 0, kn);
-            body_nyq_rows<N, T>(pk, g);
-            return;
-        }
+BFSM_HD void body_gain_inv_nyq(const GainInvNyqParams<T>& prm, Ctx& ctx) {
+    if (ctx.by() >= prm.ka_groups) {                                     // workgroup-uniform
+        const int kn = (ctx.by() - prm.ka_groups) * ctx.gx() + ctx.bx();
+        if (kn >= prm.kn_blocks) return;
+        const NyqRowsParams<T> pk{prm.ka.fhat, prm.r, prm.ka.phx, prm.ka.phy, prm.ka.phz, prm.ka.tw, prm.ka.dir0, prm.r_bstride};
+        GuestCtx<Ctx> g(ctx, 0, kn);
+        body_nyq_rows<N, T>(pk, g);
+        return;
     }
-    body_gain_inv<N, T>(prm, ctx);
+    body_gain_inv<N, T>(prm.ka, ctx);
 }
 
 // x-lines of A1', A2' in the Hermitian mode: rows idx = u + T*m of column col = y*N + z.  Only the planes 0 .. N/2 are

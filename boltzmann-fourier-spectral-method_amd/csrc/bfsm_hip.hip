@@ -238,7 +238,7 @@ template <K kind, int N, typename T>
 constexpr size_t kernel_lds_bytes() {
     if (kind == K::GainInv && pair_tile<N>()) return pair_lds_bytes<N, T>();
     if (kind == K::GainFwd) return kc_lds_bytes<N, T>();
-    if (kind == K::GainInv) return gain_inv_lds_bytes<N, T>();
+    if (kind == K::GainInvNyq) return gain_inv_lds_bytes<N, T>();
     return kind == K::Reduce ? 0 : (is_line_kind(kind) ? line_lds_bytes<N, T>() : tile_lds_bytes<N, T>());
 }
 
@@ -263,7 +263,7 @@ __global__ void __launch_bounds__((kernel_threads<kind, N>()), (kernel_min_waves
     else if constexpr (kind == K::TileFwd) body_tile_c2c<N, -1, T>(prm, ctx);
     else if constexpr (kind == K::TileInv) body_tile_c2c<N, +1, T>(prm, ctx);
     else if constexpr (kind == K::GainInv && pair_tile<N>()) body_gain_inv_pair<N, T>(prm, ctx);
-    else if constexpr (kind == K::GainInv) body_gain_inv_entry<N, T>(prm, ctx);
+    else if constexpr (kind == K::GainInv) body_gain_inv<N, T>(prm, ctx);
     else if constexpr (kind == K::GainLine) body_gain_line<N, T>(prm, ctx);
     else if constexpr (kind == K::GainFwd) body_gain_fwd<N, T>(prm, ctx);
     else if constexpr (kind == K::Reduce) body_reduce<N, T>(prm, ctx);
@@ -272,6 +272,9 @@ __global__ void __launch_bounds__((kernel_threads<kind, N>()), (kernel_min_waves
     else if constexpr (kind == K::GainLineAcc) body_gain_line_acc<N, T>(prm, ctx);
     else if constexpr (kind == K::NyqRows) body_nyq_rows<N, T>(prm, ctx);
     else if constexpr (kind == K::GainLineAccH) body_gain_line_acc_h<N, T>(prm, ctx);
+    else if constexpr (kind == K::GainInvNyq) {          // only launched where nyq_rides_along<N>()
+        if constexpr (nyq_rides_along<N>()) body_gain_inv_nyq<N, T>(prm, ctx);
+    }
 }
 
 // size-generic path (bfsm_generic.hpp): runtime sizes, 256 threads, dynamic LDS

@@ -272,7 +272,7 @@ enum class SK { Gain, Reduce };
 
 // Kernel identifiers the backend dispatches on.
 enum class K { TileFwdReal, LineFwd, LineInv, TileFwd, TileInv, GainInv, GainLine, GainFwd, Reduce, TailInv, TailLine, GainLineAcc,
-               NyqRows, GainLineAccH };
+               NyqRows, GainLineAccH, GainInvNyq };   // appended: the numeric values of the others appear in profiles
 
 // 1-D (x-axis) kernels take Wg<N>::NPL columns per workgroup, 2-D tile kernels a whole N x N tile.
 constexpr bool is_line_kind(K k) {
@@ -441,10 +441,12 @@ struct Pipeline {
             // Hermitian mode, N = 64: the chunk's 2 c.n Nyquist-row workgroups (KN) ride along as extra rows of KA's grid
             const bool kn_rides = plan.hermitian && kn_rides_along(N);
             const int kn_blocks = kn_rides ? 2 * c.n : 0, kn_rows = (kn_blocks + a_planes - 1) / a_planes;
-            GainInvParams<T> ka{fhat, a1, a2, phx, phy, phz, tw, c.dir0, c.n, per_group_a, a_bs, a_planes, warm ? 1 : 0,
-                                kn_rides ? rnyq : nullptr, r_bs, kn_blocks, ga};
+            GainInvParams<T> ka{fhat, a1, a2, phx, phy, phz, tw, c.dir0, c.n, per_group_a, a_bs, a_planes, warm ? 1 : 0};
             be->mark(BFSM_K_GAIN_INV, 2.0 * c.n * Gc * hfrac);
-            be->template launch<K::GainInv, T>(a_planes, ga + kn_rows, nb, ka, N);
+            if (kn_rides) {                     // KA + guest KN workgroups
+                GainInvNyqParams<T> kan{ka, rnyq, r_bs, kn_blocks, ga};
+                be->template launch<K::GainInvNyq, T>(a_planes, ga + kn_rows, nb, kan, N);
+            } else be->template launch<K::GainInv, T>(a_planes, ga, nb, ka, N);
             if (!plan.exact_reductions) {
                 GainLineParams<T> kb{a1, a2, tw, a_bs};
                 be->mark(BFSM_K_GAIN_LINE, 3.0 * c.n * Gc);

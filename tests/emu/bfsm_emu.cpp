@@ -163,7 +163,7 @@ struct EmuBackend {
         else if constexpr (kind == K::TileFwd) body_tile_c2c<N, -1, T>(prm, ctx);
         else if constexpr (kind == K::TileInv) body_tile_c2c<N, +1, T>(prm, ctx);
         else if constexpr (kind == K::GainInv && pair_tile<N>()) body_gain_inv_pair<N, T>(prm, ctx);
-        else if constexpr (kind == K::GainInv) body_gain_inv_entry<N, T>(prm, ctx);
+        else if constexpr (kind == K::GainInv) body_gain_inv<N, T>(prm, ctx);
         else if constexpr (kind == K::GainLine) body_gain_line<N, T>(prm, ctx);
         else if constexpr (kind == K::GainFwd) body_gain_fwd<N, T>(prm, ctx);
         else if constexpr (kind == K::Reduce) body_reduce<N, T>(prm, ctx);
@@ -172,6 +172,9 @@ struct EmuBackend {
         else if constexpr (kind == K::GainLineAcc) body_gain_line_acc<N, T>(prm, ctx);
         else if constexpr (kind == K::NyqRows) body_nyq_rows<N, T>(prm, ctx);
         else if constexpr (kind == K::GainLineAccH) body_gain_line_acc_h<N, T>(prm, ctx);
+        else if constexpr (kind == K::GainInvNyq) {
+            if constexpr (nyq_rides_along<N>()) body_gain_inv_nyq<N, T>(prm, ctx);
+        }
     }
 
     template <bfsm::K kind, int N, typename T, class P>
@@ -181,7 +184,7 @@ struct EmuBackend {
                             : (bfsm::is_line_kind(kind) ? bfsm::Wg<N>::LINE_THREADS : bfsm::Wg<N>::THREADS);
         smem.assign(pair ? bfsm::pair_lds_bytes<N, T>()
                          : kind == bfsm::K::GainFwd ? bfsm::kc_lds_bytes<N, T>()
-                         : kind == bfsm::K::GainInv ? bfsm::gain_inv_lds_bytes<N, T>()
+                         : kind == bfsm::K::GainInvNyq ? bfsm::gain_inv_lds_bytes<N, T>()
                          : (bfsm::is_line_kind(kind) ? bfsm::line_lds_bytes<N, T>() : bfsm::tile_lds_bytes<N, T>()), 0xCD);
         P copy = prm;
         for (int bz = 0; bz < gz; ++bz)

@@ -18,7 +18,7 @@ import re
 import statistics
 import sys
 
-KIND = {"5": "KA gain_inv", "6": "KB gain_line", "7": "KC gain_fwd", "11": "KB' acc", "13": "KB' acc_h"}
+KIND = {"5": "KA gain_inv", "6": "KB gain_line", "7": "KC gain_fwd", "11": "KB' acc", "13": "KB' acc_h", "14": "KA + KN"}
 d = sys.argv[1]
 import os
 f = max(glob.glob(d + "/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)      # the newest trace in the directory
@@ -56,7 +56,7 @@ for k in sorted(out):
 
 if "--transitions" in sys.argv:
     NAMES = {"0": "F1a", "1": "F1b", "5": "KA", "6": "KB", "7": "KC", "8": "reduce", "9": "tail_inv", "10": "tail_line",
-             "11": "KB'", "12": "KN", "13": "KB'H"}
+             "11": "KB'", "12": "KN", "13": "KB'H", "14": "KA+KN"}
 
     def short(name):
         m = re.search(r"\(bfsm::(S?K)\)(\d+),", name)

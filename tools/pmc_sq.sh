@@ -14,7 +14,7 @@ python3 - $TAG <<'PY' | tee $O/pmc_${TAG}_summary.txt
 import csv, glob, collections, re, os, sys
 tag = sys.argv[1]
 O = os.environ.get("GRAFT_REPO_ROOT", ".") + "/gpurun_out"
-KIND = {"5": "KA", "6": "KB", "7": "KC", "11": "KBacc", "13": "KBaccH"}
+KIND = {"5": "KA", "6": "KB", "7": "KC", "11": "KBacc", "13": "KBaccH", "14": "KAnyq"}
 for d in ("sq1", "sq2", "sq3"):
     fs = glob.glob(f"{O}/pmc_{tag}_{d}/**/*counter_collection.csv", recursive=True)
     if not fs:
