@@ -63,8 +63,8 @@ __global__ void __launch_bounds__(512, 4) probe(const d2* a1, const d2* a2, d2* 
 }
 
 template <int MODE>
-double run(const d2* a1, const d2* a2, d2* out, int n_dir) {
-    const int groups = 8, per_group = (n_dir + groups - 1) / groups;
+double run(const d2* a1, const d2* a2, d2* out, int n_dir, int groups = 8) {
+    const int per_group = (n_dir + groups - 1) / groups;
     const dim3 grid = (MODE == 0 || MODE == 1 || MODE == 4) ? dim3(N, groups) : dim3(N, n_dir);
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -98,6 +98,10 @@ int main() {
             const double gb = (m == 3) ? 2 * gb1 : gb1;
             std::printf("mode %d  %-42s %7.3f ms  %6.2f TB/s  (%.2f GB)\n", m, names[m], ms[m], gb / ms[m], gb);
         }
+        // KC's own grid at config 3: 16 groups of 48 directions = 1024 workgroups = two rounds of 512
+        const double t16 = run<0>(a1, a2, out, n_dir, 16), t32 = run<0>(a1, a2, out, n_dir, 32);
+        std::printf("mode 0  %-42s %7.3f ms  %6.2f TB/s\n", "KC pattern, 16 groups (two rounds)", t16, gb1 / t16);
+        std::printf("mode 0  %-42s %7.3f ms  %6.2f TB/s\n", "KC pattern, 32 groups (four rounds)", t32, gb1 / t32);
     }
     return 0;
 }
