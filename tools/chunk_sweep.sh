@@ -1,3 +1,5 @@
+#!/bin/bash
+# bench.py wall-clock rate (value, median of the repeats) for several --max-chunk settings at cfg3 and cfg4, twice each.
 for i in 1 2; do
 for mc in 0 384 256 192; do python3 bench.py --workload cfg3 --steps 40 --warmup 5 --no-cpu --no-exact --no-extras --repeats 3 --max-chunk $mc 2>/dev/null | python3 -c "
 import json,sys
