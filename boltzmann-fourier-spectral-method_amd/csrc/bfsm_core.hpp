@@ -258,7 +258,11 @@ template <> struct Geo<24>  { static constexpr int E = 12, T = 2; };    // two t
 template <> struct Geo<40>  { static constexpr int E = 20, T = 2; };
 
 // columns per workgroup of the line (x-axis) kernels: a row of N, or a divisor of it that keeps runs >= 384 bytes
+#ifdef BFSM_LINE_NPL_FULL     // A/B builds (tools only): whole rows of N columns per line-kernel workgroup at N = 128
+constexpr int line_npl(int n) { return n <= 64 || n == 128 ? n : (n % 64 == 0 ? 64 : n / 2); }
+#else
 constexpr int line_npl(int n) { return n <= 64 ? n : (n % 64 == 0 ? 64 : n / 2); }
+#endif
 
 // Lanes per row of threads.  Rows that do not cover whole waves are padded to the next multiple of 64 lanes at N = 40,
 // 48 and 96 (and their line-kernel column counts); a padding lane DUPLICATES the lane (ROW - N) below it -- same
@@ -499,7 +503,7 @@ struct LineParams {          // generic x-axis pass on an array [x][N*N]
 template <typename T>
 struct GainInvParams {       // KA
     const cx<T>* fhat;       // [lx][lz][ly]
-    cx<T>* a1;               // [slot][lx][y][z]
+    cx<T>* a1;               // [slot][lx][y][z]; ab_interleaved: [slot][lx][y][z][2] holding both, a2 unused
     cx<T>* a2;
     const cx<T>* phx;        // [shard directions][N] phase tables, exp(i*theta) factors; phx carries the 1/G scale
     const cx<T>* phy;
@@ -526,10 +530,12 @@ struct GainInvNyqParams {    // KA + guest KN workgroups
 
 template <typename T>
 struct GainLineParams {      // KB
-    cx<T>* a1;               // in: A1', out: P' (in place)
+    cx<T>* a1;               // in: A1' (ab_interleaved: the pairs {A1', A2'})
     const cx<T>* a2;
     const cx<T>* tw;
-    size_t a_bstride;        // batch stride (elements) of a1 / a2
+    size_t a_bstride;        // batch stride (grid points) of a1 / a2
+    cx<T>* pout;             // out: P' [slot][x][y][z] -- a1 itself (in place) unless ab_interleaved
+    size_t p_bstride;        // batch stride (elements) of pout
 };
 
 // One accumulating workgroup column of KC: a run of directions that all share the radial node r, so that beta1
@@ -747,6 +753,22 @@ template <int N, typename T> constexpr bool pipelined_pair() {
 #endif
 }
 
+// Interleaved scratch (round 4).  Where an element is 8 bytes (single precision) A1' and A2' of a grid point are stored
+// side by side, [slot][lx][y][z][2], so that KA writes and KB reads BOTH with one 16-byte access per lane: half the
+// vector-memory instructions on the CU's one memory pipe, 1-KiB instead of 512-byte runs per wave.  KA finishes tile A's
+// last step into registers, runs tile B's last step and stores the pair.  P' cannot overwrite A1' in place then (its
+// compact rows belong to other workgroups' pairs): KB writes it to a buffer of its own, [slot][x][y][z].
+// Geometry: N = 128 in single precision (config 5), the pipelined-pair form of KA; not in the Hermitian mode, whose line
+// kernel rebuilds one array at a time (its launches use the kernel kind GainInvTwo = KA with two arrays; measured with every
+// other element of the pairs read instead: KB'H 2.06 -> 2.71 ms on the 768-direction slice).  BFSM_NO_INTERLEAVE restores two arrays everywhere.
+template <int N, typename T> constexpr bool ab_interleaved() {
+#ifdef BFSM_NO_INTERLEAVE
+    return false;
+#else
+    return sizeof(T) == 4 && N == 128 && pipelined_pair<N, T>();
+#endif
+}
+
 // (Measured and rejected at N = 128 fp32, profiles/r03_ka_wide32_ab.txt, code in commit ab65758: 32 points per thread, 512 threads per
 // tile, the 2-D tile transform in three register passes -- z: 32 x 4, y: 8 x 16 -- with two exchanges and 8 barriers per
 // direction instead of three and 12.  Correct, 227 VGPRs, 6.40 against 5.35 ms: half the waves hide less than the exchanges save.)
@@ -757,8 +779,11 @@ template <int N, typename T> constexpr bool pipelined_pair() {
 // KA.  grid = (N planes lx, groups).  For each direction of the group and both signs: phase multiply
 // (compute_alpha_times_f_hat, BoltzmannCUDAKernels.cu:21-59, with the sincos hoisted into separable tables)
 // fused with the (lz,ly) -> (y,z) part of the two batched inverse transforms (CUDABoltzmannOperator.cu:156-164).
-template <int N, typename T, class Ctx>
+// PAIRS: store {A1', A2'} pairs into a1 (ab_interleaved geometries); false there only for the Hermitian mode's launches
+// (kernel kind GainInvTwo), which keep two arrays.
+template <int N, typename T, bool PAIRS = ab_interleaved<N, T>(), class Ctx>
 BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
+    static_assert(!PAIRS || ab_interleaved<N, T>(), "pair stores need the pipelined-pair form");
     constexpr int E = Wg<N>::E, TT = Wg<N>::T;
     int p, u;
     lane_coords<N, Wg<N>::ROW>(ctx, p, u);
@@ -795,20 +820,34 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
         // signs (the two tiles are live together here anyway).  Measured against the sequential form: see DESIGN.md 7.1.
         constexpr int Q = Wg<N>::Q, LS = Wg<N>::LS;
         unsigned pl = (unsigned)p * (unsigned)sizeof(cx<T>);   // this lane's byte offset inside a row
+        // Exchange addresses.  A tile beyond 64 KiB (N = 128) does not fit the 16-bit immediate offset of the LDS
+        // instructions; left to itself the compiler then keeps one address register PER ROW of the upper half (17 VGPRs of
+        // addresses in this loop, on a kernel at the 128-VGPR cap).  The rows >= N/2 are therefore addressed from a second
+        // base that the optimiser cannot fold back into the first: two registers per access pattern, immediates for the rest.
+        constexpr bool BIG = sizeof(cx<T>) * (size_t)Wg<N>::LDS_ELEMS > 65536u;
+        constexpr int HALF = N / 2;
+        const int hi = BIG ? ctx.opaque_v(HALF * LS) : HALF * LS;
+        cx<T>* const wlo = lds + u * LS + p;            // rows k TT + u        (k < E)
+        cx<T>* const whi = wlo + hi;
+        cx<T>* const rlo = lds + u * TT * LS + p;       // rows (u + TT q) TT + uu
+        cx<T>* const rhi = rlo + hi;
         auto xw_line = [&](const cx<T>* v) {
 #pragma unroll
-            for (int k1 = 0; k1 < E; ++k1) ctx.lds_st(lds + (k1 * TT + u) * LS + p, v[k1]);
+            for (int k1 = 0; k1 < E; ++k1) {
+                if (k1 * TT < HALF) ctx.lds_st(wlo + k1 * TT * LS, v[k1]);
+                else ctx.lds_st(whi + (k1 * TT - HALF) * LS, v[k1]);
+            }
         };
         auto xr_line = [&](cx<T>* w2) {
 #pragma unroll
             for (int q = 0; q < Q; ++q)
 #pragma unroll
-                for (int uu = 0; uu < TT; ++uu) w2[q * TT + uu] = ctx.lds_ld(lds + ((u + TT * q) * TT + uu) * LS + p);
+                for (int uu = 0; uu < TT; ++uu) {
+                    if (q * TT * TT < HALF) w2[q * TT + uu] = ctx.lds_ld(rlo + (q * TT * TT + uu) * LS);
+                    else w2[q * TT + uu] = ctx.lds_ld(rhi + (q * TT * TT + uu - HALF) * LS);
+                }
         };
-        auto xw_tr = [&](const cx<T>* v) {
-#pragma unroll
-            for (int m = 0; m < E; ++m) ctx.lds_st(lds + (u + TT * m) * LS + p, v[m]);
-        };
+        auto xw_tr = [&](const cx<T>* v) { xw_line(v); };      // rows u + T m: the same addresses
         auto xr_tr = [&](cx<T>* v) {
 #pragma unroll
             for (int m = 0; m < E; ++m) v[m] = ctx.lds_ld(lds + p * LS + (u + TT * m));
@@ -832,33 +871,72 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
 #endif
             }
         };
+        // Interleaved scratch: tile A's last step stays in registers (w2[q T + k2] = row u + T (q + Q k2)) ...
+        constexpr bool IL = PAIRS;
+        auto step2_keep = [&](cx<T>* w2) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                cx<T> w[TT];
+                w[0] = {(T)1, (T)0};
+#pragma unroll
+                for (int uu = 1; uu < TT; ++uu) w[uu] = twr.get(q, uu, ctx);
+                SmallDftTw<TT, +1, T, true>::run(w2 + q * TT, w);
+            }
+        };
+        // ... and leaves with tile B's: one 4 * sizeof(T)-byte store per row and lane, {A1', A2'} of the point
+        auto step2_store_pair = [&](int d, const cx<T>* wA, cx<T>* w2, unsigned pl2) {
+            cx<T>* dst = prm.a1 + 2 * (bz * prm.a_bstride + ((size_t)d * prm.planes + lxi) * N * N);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                cx<T> w[TT];
+                w[0] = {(T)1, (T)0};
+#pragma unroll
+                for (int uu = 1; uu < TT; ++uu) w[uu] = twr.get(q, uu, ctx);
+                SmallDftTw<TT, +1, T, true>::run(w2 + q * TT, w);
+#pragma unroll
+                for (int k2 = 0; k2 < TT; ++k2)   // row y = u + T (q + Q k2), z = p
+                    ctx.template st_stream_pair_at<Wg<N>::ROW % 64 == 0>(dst + 2 * (size_t)(u + TT * (q + Q * k2)) * N, pl2,
+                                                                          wA[q * TT + k2], w2[q * TT + k2]);
+#ifndef BFSM_KA_STORE_BURST
+                ctx.sched_fence();
+#endif
+            }
+        };
 #ifdef BFSM_KA_BARRIER_TIMES
         unsigned long long tbar[13] = {}, t_begin = ctx.clk();
 #define BFSM_TSYNC(k) { const unsigned long long t0_ = ctx.clk(); ctx.sync(); tbar[k] += ctx.clk() - t0_; }
 #else
 #define BFSM_TSYNC(k) ctx.sync();
 #endif
+        // per-lane phy factor and the warm-up touches: wave-uniform row pointer + 32-bit lane offset (no 64-bit address
+        // held in VGPRs across the loop: the kernel sits at the 128-VGPR cap)
+        constexpr bool ROWU = Wg<N>::ROW % 64 == 0;
         cx<T> py = {(T)0, (T)0};
-        if (d_begin < d_end) py = prm.phy[(size_t)(prm.dir0 + d_begin) * N + p];
+        if (d_begin < d_end) py = ctx.template ld_at<ROWU>(prm.phy + (size_t)(prm.dir0 + d_begin) * N, (unsigned)p * (unsigned)sizeof(cx<T>));
+        ctx.drain_loads();     // no per-iteration vmcnt(0) (= store drain) at the loop header, see DevCtx::drain_loads
         for (int d = d_begin; d < d_end; ++d) {
             const size_t b = (size_t)(prm.dir0 + d);
             const cx<T> c0 = cmul(ctx.ldc(prm.phx + b * N + lxi), py);
-            if (d + 1 < d_end) py = prm.phy[(size_t)(prm.dir0 + d + 1) * N + p];
-            T warm = (T)0;     // L2 warm-up of the phase-table rows two directions ahead (see the sequential form below)
+            pl = ctx.lane_off((unsigned)p * (unsigned)sizeof(cx<T>));     // per-iteration copy, see DevCtx::lane_off
+            if (d + 1 < d_end) py = ctx.template ld_at<ROWU>(prm.phy + (size_t)(prm.dir0 + d + 1) * N, pl);
+            T warm = (T)0, warm2 = (T)0;     // L2 warm-up of the phase-table rows two directions ahead (see the sequential form below)
             constexpr int EPL = 64 / (int)sizeof(cx<T>), LINES = N / EPL;
             const bool warming = (N % 64 == 0) && 2 * LINES <= 64 && prm.warm_tables != 0 && u == 0 && d + 2 < d_end;
             if (warming) {
                 const size_t bw = (size_t)(prm.dir0 + d + 2);
-                const int l = tid % 64;
-                const cx<T>* row = (l < LINES) ? prm.phz : prm.phy;
-                warm = row[bw * N + (size_t)(l % LINES) * EPL].x;
+                const unsigned lo = ctx.lane_off((unsigned)(tid % LINES) * 64u);      // one 64-byte line per lane
+                warm = ctx.template ld_real_at<ROWU>(prm.phz + bw * N, lo);
+                warm2 = ctx.template ld_real_at<ROWU>(prm.phy + bw * N, lo);
             }
-            pl = ctx.lane_off((unsigned)p * (unsigned)sizeof(cx<T>));     // per-iteration copy, see DevCtx::lane_off
             cx<T> va[E], vb[E], wa[E], wb[E];
+            // Phase factors formed once for both signs: 4 operations per point fewer, a second tile's worth of registers live
+            // across the first transform.  N = 128 fp32 (VALU-bound; 120 VGPRs since the exchange addresses take two registers
+            // per pattern): KA 5.12 -> 4.94 ms on the 768-direction slice of config 5.  N = 64 fp64 (124 VGPRs): 0.955 -> 0.967 ms
+            // at config 3, so not there (profiles/r04_ka_interleave_ab.txt).  BFSM_KA_SHARE_PHASE=0 / 1 forces it off / on.
 #ifdef BFSM_KA_SHARE_PHASE
-            constexpr bool SHARE = true;        // phase factors formed once for both signs: 64 operations fewer, 32 more
-#else                                           // live registers at the first transform (spills at 128 VGPRs: slower)
-            constexpr bool SHARE = false;
+            constexpr bool SHARE = (BFSM_KA_SHARE_PHASE) != 0;
+#else
+            constexpr bool SHARE = sizeof(T) == 4 && N == 128;
 #endif
 #pragma unroll
             for (int m = 0; m < E; ++m) {
@@ -895,11 +973,12 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
             BFSM_TSYNC(9); xr_line(wa); BFSM_TSYNC(10);
             xw_line(vb);
             ctx.sched_fence();
-            step2_store(prm.a1, d, wa);
+            if constexpr (IL) step2_keep(wa); else step2_store(prm.a1, d, wa);
             BFSM_TSYNC(11); xr_line(wb);
             ctx.sched_fence();
-            step2_store(prm.a2, d, wb);
-            if (warming) ctx.keep_alive(warm);
+            if constexpr (IL) step2_store_pair(d, wa, wb, ctx.lane_off((unsigned)p * (unsigned)(2 * sizeof(cx<T>))));
+            else step2_store(prm.a2, d, wb);
+            if (warming) { ctx.keep_alive(warm); ctx.keep_alive(warm2); }
         }
 #ifdef BFSM_KA_BARRIER_TIMES
 #pragma unroll
@@ -914,6 +993,7 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
         // is fetched before this direction's transforms so that its latency hides behind the butterflies.
         cx<T> py = {(T)0, (T)0};
         if (d_begin < d_end) py = prm.phy[(size_t)(prm.dir0 + d_begin) * N + p];
+        ctx.drain_loads();     // see DevCtx::drain_loads: no store drain at the top of every iteration
         for (int d = d_begin; d < d_end; ++d) {
             const size_t b = (size_t)(prm.dir0 + d);
             const cx<T> c0 = cmul(ctx.ldc(prm.phx + b * N + lxi), py);
@@ -971,6 +1051,7 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
         const int j_end = 2 * d_end;
         cx<T> py = {(T)0, (T)0};
         if (d_begin < d_end) py = prm.phy[(size_t)(prm.dir0 + d_begin) * N + p];
+        ctx.drain_loads();
         for (int j = 2 * d_begin; j < j_end; ++j) {
             const int d = j >> 1;
             const bool conj = (j & 1) != 0;
@@ -1049,6 +1130,7 @@ BFSM_HD void body_gain_inv_pair(const GainInvParams<T>& prm, Ctx& ctx) {
     if (d_end > prm.n_dir) d_end = prm.n_dir;
     cx<T> py = {(T)0, (T)0};
     if (d_begin < d_end) py = prm.phy[(size_t)(prm.dir0 + d_begin) * N + p];
+    ctx.drain_loads();
     for (int d = d_begin; d < d_end; ++d) {
         const size_t b = (size_t)(prm.dir0 + d);
         cx<T> c0 = cmul(ctx.ldc(prm.phx + b * N + lxi), py);
@@ -1086,26 +1168,34 @@ BFSM_HD void body_gain_line(const GainLineParams<T>& prm, Ctx& ctx) {
     lane_coords<NPL, Wg<N>::LROW>(ctx, p, u);
     // wave-uniform row pointers + a 32-bit lane offset: the accesses take the scalar-base addressing form, so no
     // per-access 64-bit address lives in VGPRs
-    const size_t ubase = (size_t)ctx.bz() * prm.a_bstride + (size_t)ctx.by() * N * N * N + (size_t)ctx.bx() * NPL;
-    cx<T>* A1 = prm.a1 + ubase;
-    const cx<T>* A2 = prm.a2 + ubase;
+    const size_t dcol = (size_t)ctx.by() * N * N * N + (size_t)ctx.bx() * NPL;
+    const size_t ubase = (size_t)ctx.bz() * prm.a_bstride + dcol;
     const unsigned pl = (unsigned)p * (unsigned)sizeof(cx<T>);   // lane offset in bytes
     constexpr bool UNI = Wg<N>::LROW % 64 == 0;
     cx<T>* lds = ctx.template lds<cx<T>>();
     Twiddles<N, T> twr;
     twr.load(prm.tw, u, ctx);
     cx<T> a[E], b[E];
+    if constexpr (ab_interleaved<N, T>()) {        // {A1', A2'} of a point in one access
+        const cx<T>* AB = prm.a1 + 2 * ubase;
 #pragma unroll
-    for (int m = 0; m < E; ++m) a[m] = ctx.template ld_stream_at<UNI>(A1 + (size_t)(u + TT * m) * N * N, pl);
+        for (int m = 0; m < E; ++m) ctx.template ld_stream_pair_at<UNI>(AB + 2 * (size_t)(u + TT * m) * N * N, 2 * pl, a[m], b[m]);
+    } else {
+        const cx<T>* A1 = prm.a1 + ubase;
+        const cx<T>* A2 = prm.a2 + ubase;
 #pragma unroll
-    for (int m = 0; m < E; ++m) b[m] = ctx.template ld_stream_at<UNI>(A2 + (size_t)(u + TT * m) * N * N, pl);
+        for (int m = 0; m < E; ++m) a[m] = ctx.template ld_stream_at<UNI>(A1 + (size_t)(u + TT * m) * N * N, pl);
+#pragma unroll
+        for (int m = 0; m < E; ++m) b[m] = ctx.template ld_stream_at<UNI>(A2 + (size_t)(u + TT * m) * N * N, pl);
+    }
     fft_line_np<N, NPL, +1, T, false, SYNC_PRE | SYNC_POST>(a, lds, p, u, twr, ctx);
     fft_line_np<N, NPL, +1, T, false, SYNC_POST>(b, lds, p, u, twr, ctx);
 #pragma unroll
     for (int m = 0; m < E; ++m) a[m] = cmul(a[m], b[m]);
     fft_line_np<N, NPL, -1, T, false, 0>(a, lds, p, u, twr, ctx);
+    cx<T>* P = prm.pout + (size_t)ctx.bz() * prm.p_bstride + dcol;
 #pragma unroll
-    for (int m = 0; m < E; ++m) ctx.template st_stream_at<UNI>(A1 + (size_t)(u + TT * m) * N * N, pl, a[m]);
+    for (int m = 0; m < E; ++m) ctx.template st_stream_at<UNI>(P + (size_t)(u + TT * m) * N * N, pl, a[m]);
 }
 
 // KB' (exact-reduction mode).  grid = (N rows y, segments).  FFT linearity: beta1 depends on r only and the forward
@@ -1131,10 +1221,16 @@ BFSM_HD void body_gain_line_acc(const GainLineAccParams<T>& prm, Ctx& ctx) {
     for (int d = seg.d0; d < seg.d0 + seg.n; ++d) {
         const size_t base = (size_t)ctx.bz() * prm.a_bstride + (size_t)d * N * N * N + row;
         cx<T> a[E], b[E];
+        if constexpr (ab_interleaved<N, T>()) {
 #pragma unroll
-        for (int m = 0; m < E; ++m) a[m] = ctx.template ld_stream_at<UNI>(prm.a1 + base + (size_t)(u + TT * m) * N * N, pl);
+            for (int m = 0; m < E; ++m)
+                ctx.template ld_stream_pair_at<UNI>(prm.a1 + 2 * (base + (size_t)(u + TT * m) * N * N), 2 * pl, a[m], b[m]);
+        } else {
 #pragma unroll
-        for (int m = 0; m < E; ++m) b[m] = ctx.template ld_stream_at<UNI>(prm.a2 + base + (size_t)(u + TT * m) * N * N, pl);
+            for (int m = 0; m < E; ++m) a[m] = ctx.template ld_stream_at<UNI>(prm.a1 + base + (size_t)(u + TT * m) * N * N, pl);
+#pragma unroll
+            for (int m = 0; m < E; ++m) b[m] = ctx.template ld_stream_at<UNI>(prm.a2 + base + (size_t)(u + TT * m) * N * N, pl);
+        }
         fft_line_np<N, NPL, +1, T>(a, lds, p, u, twr, ctx);
         fft_line_np<N, NPL, +1, T>(b, lds, p, u, twr, ctx);
         const T w = prm.dirw[prm.dir0 + d];
@@ -1336,7 +1432,7 @@ BFSM_HD void body_gain_line_acc_h(const GainLineAccHParams<T>& prm, Ctx& ctx) {
         const cx<T>* R = prm.r + (size_t)ctx.bz() * prm.r_bstride + (size_t)d * 4 * NQ * N;
         cx<T> a[E], b[E];
         if constexpr (N >= 128) {      // 16 points per thread: one line at a time keeps the kernel inside 128 VGPRs
-            hermitian_line_load1<N, T>(a, prm.a1 + abase, colrow, pl, p, u, lds, ctx);
+            hermitian_line_load1<N, T>(a, prm.a1 + abase, colrow, pl, p, u, lds, ctx);      // (two arrays in this mode)
             hermitian_line_fix<N, T>(a, R, y, z0, p, u, ctx);
             fft_line_np<N, NPL, +1, T>(a, lds, p, u, twr, ctx);
             hermitian_line_load1<N, T>(b, prm.a2 + abase, colrow, pl, p, u, lds, ctx);

@@ -34,6 +34,12 @@ struct DevCtx {
 #endif
         __syncthreads();
     }
+    // Waits until every vector-memory load issued so far has returned.  Placed in front of a loop that streams stores:
+    // the compiler's wait-count pass merges the loop pre-header's pending loads (the f_hat plane, needed by the first
+    // iteration) into the loop header's state and would otherwise emit s_waitcnt vmcnt(0) at the TOP OF EVERY ITERATION --
+    // on gfx9 that counter also covers stores, so every wave would drain its own previous store burst before it starts
+    // the next direction.  With the pre-header drained the header only waits for what the back edge really carries.
+    __device__ __forceinline__ void drain_loads() const { __builtin_amdgcn_s_waitcnt(0x0F70); }   // vmcnt(0), other counters free
     // nothing is scheduled across this point (bounds how many loads the compiler keeps in flight, i.e. registers)
     __device__ __forceinline__ void sched_fence() const { __builtin_amdgcn_sched_barrier(0); }
 #ifdef BFSM_KA_BARRIER_TIMES     // instrumented build (tools only): cycles every wave spends inside each barrier of KA's pair loop
@@ -170,6 +176,43 @@ struct DevCtx {
 #endif
 #pragma clang diagnostic pop
     }
+    // Interleaved scratch (ab_interleaved: element = {A1', A2'} of one grid point, 4 * sizeof(T) bytes): both values of a
+    // point in ONE global_load / global_store of twice the width (dwordx4 in fp32), same scalar-base addressing form.
+    template <bool UNI, class T>
+    __device__ __forceinline__ void ld_stream_pair_at(const cx<T>* row, unsigned byte_off, cx<T>& v0, cx<T>& v1) const {
+        typedef T vec4 __attribute__((ext_vector_type(4)));
+        typedef const unsigned char __attribute__((address_space(1))) * gptr;
+        typedef const vec4 __attribute__((address_space(1))) * gvec;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+        gptr g = (gptr)(reinterpret_cast<const unsigned char*>(row));
+        if constexpr (UNI) asm volatile("" : "+s"(g));
+        const vec4 r = __builtin_nontemporal_load((gvec)(g + byte_off));
+#pragma clang diagnostic pop
+        v0 = cx<T>{r.x, r.y};
+        v1 = cx<T>{r.z, r.w};
+    }
+    template <bool UNI, class T>
+    __device__ __forceinline__ void st_stream_pair_at(cx<T>* row, unsigned byte_off, cx<T> v0, cx<T> v1) const {
+#ifdef BFSM_KO_STORE
+        asm volatile("" ::"v"(v0.x), "v"(v0.y), "v"(v1.x), "v"(v1.y));
+        return;
+#endif
+        typedef T vec4 __attribute__((ext_vector_type(4)));
+        typedef unsigned char __attribute__((address_space(1))) * gptr;
+        typedef vec4 __attribute__((address_space(1))) * gvec;
+        vec4 r;
+        r.x = v0.x;
+        r.y = v0.y;
+        r.z = v1.x;
+        r.w = v1.y;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+        gptr g = (gptr)(reinterpret_cast<unsigned char*>(row));
+        if constexpr (UNI) asm volatile("" : "+s"(g));
+        __builtin_nontemporal_store(r, (gvec)(g + byte_off));
+#pragma clang diagnostic pop
+    }
     // cacheable (plain) variants of the row + lane-offset accessors
     template <bool UNI, class T>
     __device__ __forceinline__ cx<T> ld_at(const cx<T>* row, unsigned byte_off) const {
@@ -200,6 +243,19 @@ struct DevCtx {
         asm volatile("" : "+s"(g));
         *(gvec)(g + byte_off) = r;
 #pragma clang diagnostic pop
+    }
+    // one real of a row (cacheable): wave-uniform row pointer + 32-bit lane byte offset (the L2 warm-up touches)
+    template <bool UNI, class T>
+    __device__ __forceinline__ T ld_real_at(const cx<T>* row, unsigned byte_off) const {
+        typedef const unsigned char __attribute__((address_space(1))) * gptr;
+        typedef const T __attribute__((address_space(1))) * gval;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+        gptr g = (gptr)(reinterpret_cast<const unsigned char*>(row));
+        if constexpr (UNI) asm volatile("" : "+s"(g));
+        const T r = *(gval)(g + byte_off);
+#pragma clang diagnostic pop
+        return r;
     }
     // read-only table element through the constant address space: with a wave-uniform address the compiler
     // emits s_load (scalar data cache, SGPR result) even when the kernel also stores to global memory
@@ -274,6 +330,8 @@ __global__ void __launch_bounds__((kernel_threads<kind, N>()), (kernel_min_waves
     else if constexpr (kind == K::GainLineAccH) body_gain_line_acc_h<N, T>(prm, ctx);
     else if constexpr (kind == K::GainInvNyq) {          // only launched where nyq_rides_along<N>()
         if constexpr (nyq_rides_along<N>()) body_gain_inv_nyq<N, T>(prm, ctx);
+    } else if constexpr (kind == K::GainInvTwo) {          // only launched on ab_interleaved geometries (Hermitian mode)
+        if constexpr (ab_interleaved<N, T>()) body_gain_inv<N, T, false>(prm, ctx);
     }
 }
 

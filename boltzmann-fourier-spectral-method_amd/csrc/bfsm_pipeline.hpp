@@ -272,7 +272,8 @@ enum class SK { Gain, Reduce };
 
 // Kernel identifiers the backend dispatches on.
 enum class K { TileFwdReal, LineFwd, LineInv, TileFwd, TileInv, GainInv, GainLine, GainFwd, Reduce, TailInv, TailLine, GainLineAcc,
-               NyqRows, GainLineAccH, GainInvNyq };   // appended: the numeric values of the others appear in profiles
+               NyqRows, GainLineAccH, GainInvNyq,     // appended: the numeric values of the others appear in profiles
+               GainInvTwo };                          // KA storing two arrays on a geometry whose default is interleaved pairs
 
 // 1-D (x-axis) kernels take Wg<N>::NPL columns per workgroup, 2-D tile kernels a whole N x N tile.
 constexpr bool is_line_kind(K k) {
@@ -295,6 +296,7 @@ struct Pipeline {
     cx<T>* qhat = nullptr;
     cx<T>* a1 = nullptr;
     cx<T>* a2 = nullptr;
+    cx<T>* pp = nullptr;          // P': a1 itself (KB works in place) unless the scratch is interleaved (own buffer)
     cx<T>* slab = nullptr;
     cx<T>* tw = nullptr;
     cx<T>* phx = nullptr;
@@ -323,6 +325,9 @@ struct Pipeline {
         return true;
     }
 
+    // A1' / A2' interleaved per element in one array (bfsm_core.hpp, ab_interleaved)
+    bool pair_geometry() const { return plan.N == 128 && ab_interleaved<128, T>(); }
+    bool interleaved() const { return pair_geometry() && !plan.hermitian; }
     int a_planes = 0;        // lx planes of A1' / A2' kept per direction (N, or N/2 + 1 in the Hermitian mode)
     size_t r_per_dir() const { return (size_t)4 * (plan.N / 2 - 1) * plan.N; }
     int max_batch = 1;       // distributions evaluated per call; scratch scales with it
@@ -345,8 +350,15 @@ struct Pipeline {
         ok = ok && (qhat = (cx<T>*)be->alloc(nb * G * sizeof(cx<T>)));
         a_planes = plan.hermitian ? plan.N / 2 + 1 : plan.N;
         const size_t Gp = (size_t)a_planes * plan.N * plan.N;       // elements of A1' / A2' per direction
-        ok = ok && (a1 = (cx<T>*)be->alloc(nb * cap * Gp * sizeof(cx<T>)));
-        ok = ok && (a2 = (cx<T>*)be->alloc(nb * cap * Gp * sizeof(cx<T>)));
+        if (interleaved()) {
+            // {A1', A2'} side by side in a1; the faithful mode's KB writes P' to a buffer of its own (see ab_interleaved)
+            ok = ok && (a1 = (cx<T>*)be->alloc(2 * nb * cap * Gp * sizeof(cx<T>)));
+            if (!plan.exact_reductions) ok = ok && (pp = (cx<T>*)be->alloc(nb * cap * G * sizeof(cx<T>)));
+        } else {
+            ok = ok && (a1 = (cx<T>*)be->alloc(nb * cap * Gp * sizeof(cx<T>)));
+            ok = ok && (a2 = (cx<T>*)be->alloc(nb * cap * Gp * sizeof(cx<T>)));
+            pp = a1;
+        }
         if (plan.hermitian) ok = ok && (rnyq = (cx<T>*)be->alloc(nb * cap * r_per_dir() * sizeof(cx<T>)));
         ok = ok && (slab = (cx<T>*)be->alloc(nb * nslab * G * sizeof(cx<T>)));
         ok = ok && dev_copy(tw, t.tw) && dev_copy(phx, t.phx) && dev_copy(phy, t.phy) && dev_copy(phz, t.phz);
@@ -392,6 +404,8 @@ struct Pipeline {
     void destroy() {
         if (!be) return;
         if (small_part) { be->release(small_part); small_part = nullptr; }
+        if (pp && pp != a1) be->release(pp);
+        pp = nullptr;
         void* ptrs[] = {fhat, tg, tl, qhat, a1, a2, slab, tw, phx, phy, phz, dirw, beta1, beta2, segs, pseg, segs_unit, ones, rnyq};
         for (void* p : ptrs) if (p) be->release(p);
         fhat = tg = tl = qhat = a1 = a2 = slab = tw = phx = phy = phz = nullptr;
@@ -452,12 +466,14 @@ struct Pipeline {
             if (kn_rides) {                     // KA + guest KN workgroups
                 GainInvNyqParams<T> kan{ka, rnyq, r_bs, kn_blocks, ga};
                 be->template launch<K::GainInvNyq, T>(a_planes, ga + kn_rows, nb, kan, N);
-            } else be->template launch<K::GainInv, T>(a_planes, ga, nb, ka, N);
+            } else if (pair_geometry() && !interleaved()) be->template launch<K::GainInvTwo, T>(a_planes, ga, nb, ka, N);
+            else be->template launch<K::GainInv, T>(a_planes, ga, nb, ka, N);
             if (!plan.exact_reductions) {
-                GainLineParams<T> kb{a1, a2, tw, a_bs};
+                const size_t p_bs = interleaved() ? cap * G : a_bs;
+                GainLineParams<T> kb{a1, a2, tw, a_bs, pp, p_bs};
                 be->mark(BFSM_K_GAIN_LINE, 3.0 * c.n * Gc);
                 be->template launch<K::GainLine, T>(line_blocks(), c.n, nb, kb, N);
-                GainFwdParams<T> kc{a1, slab, dirw, segs, tw, c.dir0, c.seg0, a_bs, s_bs};
+                GainFwdParams<T> kc{pp, slab, dirw, segs, tw, c.dir0, c.seg0, p_bs, s_bs};
                 be->mark(BFSM_K_GAIN_FWD, 1.0 * c.n * Gc);
                 be->template launch<K::GainFwd, T>(N, c.n_seg, nb, kc, N);
             } else if (!plan.hermitian) {

@@ -48,8 +48,22 @@ struct EmuCtx {
     template <bool UNI, class U> void st_stream_at(U* row, unsigned byte_off, U v) const {
         *reinterpret_cast<U*>(reinterpret_cast<unsigned char*>(row) + byte_off) = v;
     }
+    template <bool UNI, class U> void ld_stream_pair_at(const U* row, unsigned byte_off, U& v0, U& v1) const {
+        const U* q = reinterpret_cast<const U*>(reinterpret_cast<const unsigned char*>(row) + byte_off);
+        v0 = q[0];
+        v1 = q[1];
+    }
+    template <bool UNI, class U> void st_stream_pair_at(U* row, unsigned byte_off, U v0, U v1) const {
+        U* q = reinterpret_cast<U*>(reinterpret_cast<unsigned char*>(row) + byte_off);
+        q[0] = v0;
+        q[1] = v1;
+    }
+    template <bool UNI, class U> auto ld_real_at(const U* row, unsigned byte_off) const {
+        return reinterpret_cast<const U*>(reinterpret_cast<const unsigned char*>(row) + byte_off)->x;
+    }
     void sync();       // workgroup barrier
     void sched_fence() const {}   // compiler scheduling hint on the device; nothing to do on the host
+    void drain_loads() const {}   // wait-count hygiene on the device; nothing to do on the host
     int opaque(int v) const { return v; }
     int opaque_v(int v) const { return v; }
     unsigned lane_off(unsigned v) const { return v; }
@@ -174,6 +188,8 @@ struct EmuBackend {
         else if constexpr (kind == K::GainLineAccH) body_gain_line_acc_h<N, T>(prm, ctx);
         else if constexpr (kind == K::GainInvNyq) {
             if constexpr (nyq_rides_along<N>()) body_gain_inv_nyq<N, T>(prm, ctx);
+        } else if constexpr (kind == K::GainInvTwo) {
+            if constexpr (ab_interleaved<N, T>()) body_gain_inv<N, T, false>(prm, ctx);
         }
     }
 
