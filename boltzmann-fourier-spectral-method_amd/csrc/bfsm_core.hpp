@@ -257,11 +257,15 @@ template <> struct Geo<80>  { static constexpr int E = 20, T = 4; };    // prime
 template <> struct Geo<24>  { static constexpr int E = 12, T = 2; };    // two threads per line (48-thread tiles)
 template <> struct Geo<40>  { static constexpr int E = 20, T = 2; };
 
-// columns per workgroup of the line (x-axis) kernels: a row of N, or a divisor of it that keeps runs >= 384 bytes
-#ifdef BFSM_LINE_NPL_FULL     // A/B builds (tools only): whole rows of N columns per line-kernel workgroup at N = 128
-constexpr int line_npl(int n) { return n <= 64 || n == 128 ? n : (n % 64 == 0 ? 64 : n / 2); }
-#else
+// columns per workgroup of the line (x-axis) kernels: a row of N, or a divisor of it that keeps runs >= 384 bytes; at
+// N = 32 TWO adjacent rows of the inner N * N space (64 contiguous columns), so that a row of threads is a whole wave:
+// one u per wave, twiddles through the scalar cache, scalar-base streams in 1-KiB runs -- what body_gain_inv_pair gave KA
+// (round 4; BFSM_NO_LINE_PAIR_32 restores 32 columns).  (N = 128 with whole rows of 128 columns, 1024-thread workgroups,
+// one per CU: KB 6.55 -> 7.5 ms on the 768-direction slice of config 5, profiles/r04_ka_interleave_ab2.txt.)
+#ifdef BFSM_NO_LINE_PAIR_32
 constexpr int line_npl(int n) { return n <= 64 ? n : (n % 64 == 0 ? 64 : n / 2); }
+#else
+constexpr int line_npl(int n) { return n == 32 ? 64 : (n <= 64 ? n : (n % 64 == 0 ? 64 : n / 2)); }
 #endif
 
 // Lanes per row of threads.  Rows that do not cover whole waves are padded to the next multiple of 64 lanes at N = 40,
@@ -290,7 +294,7 @@ struct Wg {
     // N rows for the exchanges; N + 2 so that the Hermitian line kernel can stage the stored halves (N/2 + 1 rows) of
     // both arrays side by side
     static constexpr int LINE_LDS_ELEMS = (N + 2) * (NPL + 1);
-    static_assert(E * T == N && Q * T == E && N % NPL == 0, "geometry");
+    static_assert(E * T == N && Q * T == E && (N * N) % NPL == 0 && (N % NPL == 0 || NPL % N == 0), "geometry");
 };
 
 // (column p, line share u) of this thread in a row of ROWW lanes serving W columns (see row_pad)
@@ -624,7 +628,7 @@ struct TailInvParams {       // tail step 1: plane inverse transforms of Q_hat a
     const cx<T>* fhat;
     const T* beta2;          // [n2max+1], includes the 1/G scale
     cx<T>* tg;               // [lx][y][z]
-    cx<T>* tl;
+    long long tl_off;        // the loss plane's array, as an element offset from tg (tl - tg)
     const cx<T>* tw;
     // n_segs >= 0: the gain plane is formed here from the write-once slabs (the reduce of ReduceParams fused into
     // the load, same summation order, qhat not touched); n_segs < 0: read it from qhat.
@@ -1387,9 +1391,8 @@ BFSM_HD void hermitian_line_load1(cx<T>* a, const cx<T>* A1, int colrow, unsigne
 }
 
 template <int N, typename T, class Ctx>
-BFSM_HD void hermitian_line_fix(cx<T>* v, const cx<T>* R, int y, int z0, int p, int u, Ctx& ctx) {
+BFSM_HD void hermitian_line_fix(cx<T>* v, const cx<T>* R, int y, int z, int u, Ctx& ctx) {
     constexpr int E = Wg<N>::E, TT = Wg<N>::T, NQ = N / 2 - 1, H = N / 2, MS = E / 2;
-    const int z = z0 + p;                                   // z0: first z of the block (uniform)
     const T sy = (y & 1) ? (T)-1 : (T)1, sz = (z & 1) ? (T)-1 : (T)1;
 #pragma unroll
     for (int m = MS; m < E; ++m) {
@@ -1420,9 +1423,11 @@ BFSM_HD void body_gain_line_acc_h(const GainLineAccHParams<T>& prm, Ctx& ctx) {
     int gbx, gby;
     xcd_rows(ctx, gbx, gby);
     const Segment seg = prm.segs[prm.seg0 + gby];
-    constexpr int BPR = N / NPL;                               // column blocks per row of N
-    const int y = gbx / BPR, z0 = (gbx % BPR) * NPL;           // y, z0 are uniform over the workgroup; z = z0 + p
-    const int colrow = y * N + z0;
+    // first column of the block in the inner N * N space; (y, z) of this lane's column.  A block is a piece of one row
+    // (y uniform over the workgroup) or, at N = 32, two whole rows (y = y0 + p / N)
+    const int colrow = gbx * NPL;
+    const int y = NPL <= N ? colrow / N : colrow / N + p / N;
+    const int z = NPL <= N ? colrow % N + p : p % N;
     const unsigned pl = (unsigned)p * (unsigned)sizeof(cx<T>);
     cx<T> acc[E];
 #pragma unroll
@@ -1433,16 +1438,16 @@ BFSM_HD void body_gain_line_acc_h(const GainLineAccHParams<T>& prm, Ctx& ctx) {
         cx<T> a[E], b[E];
         if constexpr (N >= 128) {      // 16 points per thread: one line at a time keeps the kernel inside 128 VGPRs
             hermitian_line_load1<N, T>(a, prm.a1 + abase, colrow, pl, p, u, lds, ctx);      // (two arrays in this mode)
-            hermitian_line_fix<N, T>(a, R, y, z0, p, u, ctx);
+            hermitian_line_fix<N, T>(a, R, y, z, u, ctx);
             fft_line_np<N, NPL, +1, T>(a, lds, p, u, twr, ctx);
             hermitian_line_load1<N, T>(b, prm.a2 + abase, colrow, pl, p, u, lds, ctx);
-            hermitian_line_fix<N, T>(b, R + (size_t)2 * NQ * N, y, z0, p, u, ctx);
+            hermitian_line_fix<N, T>(b, R + (size_t)2 * NQ * N, y, z, u, ctx);
             fft_line_np<N, NPL, +1, T>(b, lds, p, u, twr, ctx);
         } else {
             hermitian_lines_load<N, T>(a, b, prm.a1 + abase, prm.a2 + abase, colrow, pl, p, u, lds, ctx);
-            hermitian_line_fix<N, T>(a, R, y, z0, p, u, ctx);
+            hermitian_line_fix<N, T>(a, R, y, z, u, ctx);
             fft_line_np<N, NPL, +1, T>(a, lds, p, u, twr, ctx);
-            hermitian_line_fix<N, T>(b, R + (size_t)2 * NQ * N, y, z0, p, u, ctx);
+            hermitian_line_fix<N, T>(b, R + (size_t)2 * NQ * N, y, z, u, ctx);
             fft_line_np<N, NPL, +1, T>(b, lds, p, u, twr, ctx);
         }
         const T w = prm.dirw[prm.dir0 + d];
@@ -1553,6 +1558,9 @@ BFSM_HD void body_gain_fwd(const GainFwdParams<T>& prm, Ctx& ctx) {
     for (int m = 0; m < E; ++m) dst[(u + TT * m) * N + p] = acc[m];   // [lz = u + T m][ly = p]
 }
 
+// (Measured and rejected at N = 32, profiles/r04_n32_pairs_ab.txt, code in the commit before this note: KC on a PAIR of
+// x-planes -- a 32 x 64 panel by 256 threads, one u per wave, scalar-base streams, the counterpart of body_gain_inv_pair --
+// runs config 2's KC in 57 - 59 us against 39 us for the 128-thread tiles: half as many workgroups to stream with.)
 // Reduce.  One thread per spectral point.  Applies beta1 (the per-point factor of BoltzmannCUDAKernels.cu:113-114)
 // and sums the write-once slabs in a fixed order (deterministic; replaces the atomicAdd pair of cu:120-121).
 template <int N, typename T, class Ctx>
@@ -1601,21 +1609,18 @@ BFSM_HD void body_tail_inv(const TailInvParams<T>& prm, Ctx& ctx) {
         // Q_hat plane = sum over slabs of beta1[r(slab)][|l|^2] * slab, in the order of body_reduce (bitwise the same)
         const size_t G = (size_t)N * N * N;
         const int mx = mode_of(lxi, N), my = mode_of(p, N);
-        int n2[E];
-#pragma unroll
-        for (int m = 0; m < E; ++m) {
-            const int mz = mode_of(u + TT * m, N);
-            n2[m] = mx * mx + my * my + mz * mz;
-            v[m] = {(T)0, (T)0};
-        }
+        const int n2xy = mx * mx + my * my;        // |l|^2 = n2xy + mz^2 is formed at the point of use (an index array of E
+#pragma unroll                                     // entries held across the slab loop went to scratch: 24 B per lane)
+        for (int m = 0; m < E; ++m) v[m] = {(T)0, (T)0};
         const cx<T>* sl = prm.slab + (size_t)ctx.bz() * prm.slab_bstride + (size_t)lxi * N * N;
 #pragma unroll 2
         for (int c = 0; c < prm.n_segs; ++c) {
-            const T* b1row = prm.beta1 + (size_t)prm.segs[c].r * prm.n2stride;
+            const T* b1row = prm.beta1 + (size_t)prm.segs[c].r * prm.n2stride + n2xy;
 #pragma unroll
             for (int m = 0; m < E; ++m) {
                 const cx<T> t = sl[(size_t)c * G + (u + TT * m) * N + p];
-                const T b1 = b1row[n2[m]];
+                const int mz = mode_of(u + TT * m, N);
+                const T b1 = b1row[mz * mz];
                 v[m].x += b1 * t.x;
                 v[m].y += b1 * t.y;
             }
@@ -1634,7 +1639,9 @@ BFSM_HD void body_tail_inv(const TailInvParams<T>& prm, Ctx& ctx) {
         }
     }
     fft_tile<N, +1, T>(v, lds, p, u, twr, ctx);
-    cx<T>* dst = (loss ? prm.tl : prm.tg) + pbase;
+    // (the loss plane is addressed as tg + tl_off: a select between the two pointers was lowered to an indexed load from a
+    // private copy of the parameter block -- 24 bytes of scratch per lane in every instantiation)
+    cx<T>* dst = prm.tg + (loss ? prm.tl_off : 0) + pbase;
 #pragma unroll
     for (int m = 0; m < E; ++m) dst[(u + TT * m) * N + p] = v[m];
 }

@@ -415,7 +415,7 @@ struct Pipeline {
     }
 
     double cbytes() const { return (double)sizeof(cx<T>); }
-    int line_blocks() const { return plan.N * (plan.N / line_npl(plan.N)); }   // Wg<N>::NPL columns per workgroup
+    int line_blocks() const { return plan.N * plan.N / line_npl(plan.N); }   // Wg<N>::NPL columns per workgroup
     static bool kn_rides_along(int n) { return n == 64 && nyq_rides_along<64>(); }
 
     // f_hat = FFT(f), then the gain term of this shard into qhat (partial Q_gain_hat, spectral layout).
@@ -512,7 +512,7 @@ struct Pipeline {
         const int N = plan.N;
         const double Gc = (double)plan.G() * cbytes() * nb;
         const size_t s_bs = (slab_count ? slab_count : 1) * plan.G();
-        TailInvParams<T> ta{qhat, fhat, beta2, tg, tl, tw, slab, beta1, segs, from_slabs ? (int)slab_count : -1,
+        TailInvParams<T> ta{qhat, fhat, beta2, tg, (long long)(tl - tg), tw, slab, beta1, segs, from_slabs ? (int)slab_count : -1,
                             plan.n2stride, s_bs};
         be->mark(BFSM_K_TAIL, ((with_loss ? 4.0 : 2.0) + (from_slabs ? (double)slab_count - 1.0 : 0.0)) * Gc);
         be->template launch<K::TailInv, T>(N, with_loss ? 2 : 1, nb, ta, N);
