@@ -208,6 +208,11 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        # the group the measurement runs on must be the one that was asked for: never fall back to fewer ranks
+        if dist.get_world_size() != args.gpus or dist.get_rank() != rank:
+            print(f"bench.py: process group reports {dist.get_world_size()} rank(s) (this one {dist.get_rank()}), "
+                  f"--gpus {args.gpus} / RANK {rank} were asked for", file=sys.stderr)
+            sys.exit(6)
 
     w = WORKLOADS[args.workload]
     nv, n_gl, n_sph, prec = w["nv"], w["n_gl"], w["n_sph"], (args.precision or w["precision"])
@@ -228,6 +233,20 @@ def main():
         op.setExactReductions(exact, hermitian=exact)
         op.initialize()
         return op
+
+    # every rank's shard and device, gathered once (reported in config; the shards must tile the B directions)
+    my_shard = bfsm.shard_range(B, rank, world) if world > 1 else (0, B)
+    rank_info = [{"rank": rank, "device": dev, "directions": my_shard[1] - my_shard[0]}]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, rank_info[0])
+        rank_info = sorted(gathered, key=lambda r: r["rank"])
+        if len(rank_info) != world or sum(r["directions"] for r in rank_info) != B:
+            print(f"bench.py: the ranks' shards do not tile the {B} directions: {rank_info}", file=sys.stderr)
+            sys.exit(6)
+        if backend == "nccl" and len({r["device"] for r in rank_info}) != world:
+            print(f"bench.py: two ranks share a device: {rank_info}", file=sys.stderr)
+            sys.exit(6)
 
     f = torch.from_numpy(f_h).cuda()
     Q = torch.empty_like(f)
@@ -430,7 +449,10 @@ def main():
             "dtype": "f64" if prec == 64 else "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: N={nv}^3 grid, M_gl={n_gl}, {w['design']} ({n_sph} pts), "
                                    f"B={B} directions, BKW f (t=6.5), Maxwell molecules",
-                       "directions_per_gpu": B // world, "parallelism": f"direction-shard x{world} + 1 all-reduce",
+                       "directions_per_gpu": B // world,
+                       "directions_per_gpu_min": min(r["directions"] for r in rank_info),
+                       "directions_per_gpu_max": max(r["directions"] for r in rank_info),
+                       "rank_devices": [r["device"] for r in rank_info], "parallelism": f"direction-shard x{world} + 1 all-reduce",
                        "timing": "in-order: evaluation i+1 starts after evaluation i and its collective have finished",
                        "collective_overlap": False, "collective": collective,
                        # every direction: its own two inverse transforms and the x part of its forward transform; the

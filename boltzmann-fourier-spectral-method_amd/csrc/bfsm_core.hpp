@@ -990,6 +990,7 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
         ctx.dbg_add(13, ctx.clk() - t_begin);      // the wave's whole direction loop
         ctx.dbg_add(14, 1);                        // waves
 #endif
+#undef BFSM_TSYNC
     } else if constexpr (N >= 64 && KEEP) {
         // One iteration = one direction; both signs are produced by the same code with the sign a compile-time flag
         // (e^{+-i theta} / G = (phx[lx] * phy[ly = p]) * phz[lz = u + T m], conjugated for sign 1), so no per-point select

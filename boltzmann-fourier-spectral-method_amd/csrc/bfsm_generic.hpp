@@ -1,8 +1,8 @@
 // bfsm_generic.hpp -- size-generic path of the collision operator: any even Nvx, Nvy, Nvz <= 256 whose prime factors
-// are 2, 3, 5, 7, 11, 13 (non-cubic boxes, N = 24, 80, 112, ...), which the reference plans with cufftPlan3d / cufftPlanMany
+// are 2, 3, 5, 7, 11, 13 (non-cubic boxes, N = 20, 112, 160, ...), which the reference plans with cufftPlan3d / cufftPlanMany
 // (Collisions/CUDABoltzmannOperator.cu:86-100) and fftw_plan_dft_3d (Collisions/FFTWBoltzmannOperator.cpp:64-65).
 //
-// The cubic grids N in {16, 32, 48, 64, 96, 128} run on the fused three-kernel pipeline of bfsm_core.hpp (6 array passes
+// The cubic grids N in {16, 24, 32, 40, 48, 64, 80, 96, 128} run on the fused three-kernel pipeline of bfsm_core.hpp (6 array passes
 // per direction); everything else runs here: one batched 1-D mixed-radix Stockham pass per axis, transformed in LDS, with
 // the pointwise steps of the reference fused into the pass that touches the data first
 //     phase multiply (compute_alpha_times_f_hat, BoltzmannCUDAKernels.cu:21-59)  -> load side of the first inverse pass

@@ -16,6 +16,15 @@
 #define BFSM_F32_N64_WAVES 4
 #endif
 
+// Builds that compute WRONG results on purpose (knock-outs: no barriers / no LDS traffic / no stores / no butterflies) or
+// carry instrumentation exist for timing experiments only (tools/).  They must be asked for explicitly: a stray -D or a
+// macro-name collision in an embedding build cannot silently produce a library without barriers.  A tools build says so in
+// bfsm_backend_name().
+#if (defined(BFSM_KO_SYNC) || defined(BFSM_KO_LDS) || defined(BFSM_KO_STORE) || defined(BFSM_KO_DFT) || defined(BFSM_KA_BARRIER_TIMES)) && \
+    !defined(BFSM_TOOLS_BUILD)
+#error "BFSM_KO_* / BFSM_KA_BARRIER_TIMES are for tools-only builds: add -DBFSM_TOOLS_BUILD (the library then reports itself as a tools build)"
+#endif
+
 namespace bfsm {
 
 // ---- device execution context ---------------------------------------------------------------------------------
@@ -491,7 +500,6 @@ struct bfsm_plan {
     struct Pending { hipStream_t key; hipEvent_t ev; };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> spare_events;
-    static constexpr size_t MAX_PENDING = 64;
 };
 
 static thread_local std::string g_create_error;
@@ -533,7 +541,11 @@ static int check_hip(bfsm_plan* h, const char* where) {
 
 extern "C" {
 
+#ifdef BFSM_TOOLS_BUILD
+const char* bfsm_backend_name(void) { return "HIP (tools build: timing experiments, results not valid)"; }
+#else
 const char* bfsm_backend_name(void) { return "HIP"; }
+#endif
 int bfsm_version(void) { return BFSM_VERSION; }
 
 const char* bfsm_last_error(bfsm_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
@@ -618,8 +630,9 @@ static int enter(bfsm_plan* h, const DeviceGuard& g, void* stream) {
 
 // Common epilogue of the entry points that enqueue work: the launch status of this call, then one event record behind
 // the call so that bfsm_synchronize can wait for it without ever touching the caller's stream handle again.  Never
-// blocks and never queries (an *_async entry point only enqueues); nothing is recorded while the stream is being
-// captured into a graph (a captured launch does not run, and a captured event could not be waited for).
+// blocks: one capture-status query (hipStreamIsCapturing, host-side) and one hipEventRecord (hipEventCreate on the first
+// use of a stream); nothing is recorded while the stream is being captured into a graph (a captured launch does not run,
+// and a captured event could not be waited for) -- replays of such a graph are the caller's to synchronise.
 static int leave(bfsm_plan* h, const char* where) {
     int rc = check_hip(h, where);
     if (rc) return rc;
@@ -628,11 +641,7 @@ static int leave(bfsm_plan* h, const char* where) {
     if (cap != hipStreamCaptureStatusNone) return BFSM_OK;
     bfsm_plan::Pending* slot = nullptr;
     for (auto& pe : h->pending) if (pe.key == h->be.stream) slot = &pe;
-    if (!slot) {
-        if (h->pending.size() >= bfsm_plan::MAX_PENDING) {   // bounded: stop tracking the least recently added stream
-            h->spare_events.push_back(h->pending.front().ev);
-            h->pending.erase(h->pending.begin());
-        }
+    if (!slot) {          // one entry per distinct stream since the last bfsm_synchronize: no work is ever left untracked
         hipEvent_t ev = nullptr;
         if (!h->spare_events.empty()) { ev = h->spare_events.back(); h->spare_events.pop_back(); }
         else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess)

@@ -449,10 +449,12 @@ struct Pipeline {
             // one resident wave of workgroups, except at N = 64: two rounds of half-length workgroups let the CUs that
             // finish early take more of them (measured, same box, alternating builds: KA 3.25 - 3.28 -> 3.17 - 3.20 ms at
             // config 4, 0.99 - 1.00 -> 0.98 ms at config 3, no change at N = 128: profiles/r03_ka_rounds_ab.txt)
-#ifndef BFSM_KA_GROUPS_MULT
-#define BFSM_KA_GROUPS_MULT (N == 64 ? 2 : 1)
+#ifdef BFSM_KA_GROUPS_MULT          // A/B builds (tools only): rounds of KA workgroups
+            const int ka_rounds = (BFSM_KA_GROUPS_MULT);
+#else
+            const int ka_rounds = N == 64 ? 2 : 1;
 #endif
-            const int groups_a = (tw_ / a_planes > 0 ? tw_ / a_planes : 1) * (BFSM_KA_GROUPS_MULT);
+            const int groups_a = (tw_ / a_planes > 0 ? tw_ / a_planes : 1) * ka_rounds;
             const int per_group_a = (c.n + groups_a - 1) / groups_a;
             // phase tables beyond ~3 MiB do not stay in an XCD's L2 next to the streams: KA touches the rows ahead
             // (N = 64, config 4: 3 x 2.4 MiB of tables, KA 3.88 -> 3.66 ms; N = 128, config 5: 62 -> 52 ms)

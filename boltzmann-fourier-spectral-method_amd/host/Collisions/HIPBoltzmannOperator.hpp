@@ -61,6 +61,7 @@ public:
     // The same call returning the C-ABI status instead of print-and-exit (for callers that own the failure policy, e.g.
     // the device threads of the multi-GPU operator); lastError() is the message of the last non-zero status.
     int collidePartialStatus(double* Q, const double* f_in, bool with_loss, void* stream = nullptr) noexcept;
+    int collideBatchPartialStatus(double* Q, const double* f_in, int n_batch, bool with_loss, void* stream = nullptr) noexcept;
     const char* lastError() const noexcept;
     void* qhatBuffer(size_t* n_elems, int* precision) const;
     void synchronize();

@@ -14,7 +14,8 @@
 // xGMI sums the real Q into the caller's buffer.  With one device no RCCL call is made.
 // Each device is driven by its own host thread (created by initialize()), so the devices' launch sequences and their
 // two RCCL calls are issued concurrently; the calling thread only publishes (Q, f) and waits.  f must be complete, or
-// enqueued on the first device's default stream (what the reference's driver does), when the call is made.
+// enqueued on the first device's legacy default stream (what the reference's driver does), when the call is made; a
+// producer on any other stream is named with setInputStream().
 // No HIP or RCCL type appears in this header; the implementation is host/HIPMultiGPUBoltzmannOperator.cpp.
 #pragma once
 #include <memory>
@@ -25,6 +26,7 @@
 #include "BoltzmannOperator.hpp"
 #include "../Quadratures/GaussLegendre.hpp"
 #include "../Quadratures/SphericalDesign.hpp"
+#include "bfsm.h"
 
 struct HIP_MultiGPU_Backend {};
 
@@ -43,13 +45,28 @@ public:
     void setPrecision(int bits);                                // 64 (default) or 32
     void setExactReductions(bool on, bool hermitian = false);   // opt-in exact work reductions (include/bfsm.h)
     void setForceCollectives(bool on);                          // use RCCL even with a single device (tests)
+    void setMaxChunk(int n);                                    // directions resident at once per device (0: default)
+    void setMaxBatch(int n);                                    // distributions per computeCollisionBatch call
+    void setProfiling(bool on);                                 // per-kernel events on every device (counters())
+    void setTimeoutSeconds(double s);                           // watchdog of a blocking call (default 300 s; 0: off)
+    // The stream ON THE FIRST DEVICE on which the caller produces f (may be changed between calls).  Default: none --
+    // the operator's stream on that device is a blocking stream, i.e. ordered behind the legacy default stream only (what
+    // the reference's driver uses); f produced on any other (non-blocking) stream must be complete when the call is made,
+    // or be named here: the broadcast then waits for an event recorded on it at the call.
+    void setInputStream(void* hip_stream);
+    void clearInputStream();
 
     void initialize() override;
     std::string getBackendName() const override { return "HIP"; }
     void computeCollision(double* Q, const double* f_in) override;      // device pointers on devices()[0], blocking
     void operator()(double* Q, const double* f_in) override { computeCollision(Q, f_in); }
 
+    // n_batch <= setMaxBatch() distributions, [n_batch][Nvx*Nvy*Nvz] device arrays on devices()[0]: one broadcast, one
+    // batched shard evaluation per device, ONE reduce
+    void computeCollisionBatch(double* Q, const double* f_in, int n_batch);
+
     const std::vector<int>& devices() const;
+    bfsm_counters counters(int device_index) const;             // of the device_index-th device of devices()
 
 private:
     struct Impl;

@@ -71,6 +71,10 @@ int BoltzmannOperator<HIP_Backend>::collidePartialStatus(double* Q, const double
     return bfsm_collide_partial_async(handle_, Q, f_in, with_loss ? 1 : 0, stream);
 }
 
+int BoltzmannOperator<HIP_Backend>::collideBatchPartialStatus(double* Q, const double* f_in, int n_batch, bool with_loss, void* stream) noexcept {
+    return bfsm_collide_batch_partial_async(handle_, Q, f_in, n_batch, with_loss ? 1 : 0, stream);
+}
+
 const char* BoltzmannOperator<HIP_Backend>::lastError() const noexcept { return bfsm_last_error(handle_); }
 
 void* BoltzmannOperator<HIP_Backend>::qhatBuffer(size_t* n_elems, int* precision) const {

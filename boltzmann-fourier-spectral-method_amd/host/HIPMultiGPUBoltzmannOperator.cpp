@@ -13,7 +13,9 @@ namespace {
 
 struct HipRcclRuntime {
     using Stream = hipStream_t;
+    using Event = hipEvent_t;
     using Comm = ncclComm_t;
+    using Counters = bfsm_counters;
     using Operator = BoltzmannOperator<HIP_Backend>;
 
     static const char* hip(hipError_t e) { return e == hipSuccess ? nullptr : hipGetErrorString(e); }
@@ -28,6 +30,10 @@ struct HipRcclRuntime {
     static void stream_destroy(Stream s) { (void)hipStreamDestroy(s); }
     static const char* stream_sync(Stream s) { return hip(hipStreamSynchronize(s)); }
     static void* stream_handle(Stream s) { return static_cast<void*>(s); }
+    static const char* event_create(Event* e) { return hip(hipEventCreateWithFlags(e, hipEventDisableTiming)); }
+    static void event_destroy(Event e) { if (e) (void)hipEventDestroy(e); }
+    static const char* event_record_on(Event e, void* producer) { return hip(hipEventRecord(e, static_cast<hipStream_t>(producer))); }
+    static const char* stream_wait(Stream s, Event e) { return hip(hipStreamWaitEvent(s, e, 0)); }
     static const char* comm_init_all(Comm* c, int P, const int* devices) { return rccl(ncclCommInitAll(c, P, devices)); }
     static void comm_destroy(Comm c) { if (c) (void)ncclCommDestroy(c); }
     static const char* broadcast(double* buf, size_t n, int root, Comm c, Stream s) {
@@ -65,6 +71,16 @@ void BoltzmannOperator<HIP_MultiGPU_Backend>::setExactReductions(bool on, bool h
     impl_->hermitian = on && hermitian;
 }
 void BoltzmannOperator<HIP_MultiGPU_Backend>::setForceCollectives(bool on) { impl_->force_collectives = on; }
+void BoltzmannOperator<HIP_MultiGPU_Backend>::setMaxChunk(int n) { impl_->max_chunk = n; }
+void BoltzmannOperator<HIP_MultiGPU_Backend>::setMaxBatch(int n) { impl_->max_batch = n; }
+void BoltzmannOperator<HIP_MultiGPU_Backend>::setProfiling(bool on) { impl_->profiling = on; }
+void BoltzmannOperator<HIP_MultiGPU_Backend>::setInputStream(void* s) { impl_->input_stream = s; impl_->has_input_stream = true; }
+void BoltzmannOperator<HIP_MultiGPU_Backend>::clearInputStream() { impl_->input_stream = nullptr; impl_->has_input_stream = false; }
+void BoltzmannOperator<HIP_MultiGPU_Backend>::setTimeoutSeconds(double s) { impl_->timeout_s = s; }
+bfsm_counters BoltzmannOperator<HIP_MultiGPU_Backend>::counters(int index) const { return impl_->counters(index); }
+void BoltzmannOperator<HIP_MultiGPU_Backend>::computeCollisionBatch(double* Q, const double* f_in, int n_batch) {
+    impl_->compute_batch(Q, f_in, n_batch);
+}
 const std::vector<int>& BoltzmannOperator<HIP_MultiGPU_Backend>::devices() const { return impl_->ready ? impl_->active : impl_->devs; }
 
 void BoltzmannOperator<HIP_MultiGPU_Backend>::initialize() { impl_->initialize(); }

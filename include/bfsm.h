@@ -15,10 +15,14 @@
  *     they reuse the scratch.  Different handles are independent and may be driven from different threads / streams.
  *   - every call makes the handle's device current for its own duration and restores the calling thread's current
  *     device before it returns.
- *   - the *_async entry points only enqueue kernels on the given stream (no allocation, no synchronisation, no
- *     stream or event query), so after one evaluation outside a capture they can be captured into a HIP graph.  Outside
- *     a capture each call also records one handle-owned event behind its work (what bfsm_synchronize waits for); the
- *     caller's stream handle is never used after the call returns, so the caller may destroy the stream at any time.
+ *   - the *_async entry points only enqueue kernels on the given stream: no allocation and no synchronisation after the
+ *     first evaluation; per call one host-side capture-status query (hipStreamIsCapturing) and, outside a capture, one
+ *     record of a handle-owned event behind the call's work (what bfsm_synchronize waits for; the event of a stream is
+ *     created at its first use).  After one evaluation outside a capture they can therefore be captured into a HIP graph;
+ *     nothing is recorded during a capture, so replays of such a graph are the caller's to synchronise.  The caller's
+ *     stream handle is never used after the call returns: the caller may destroy the stream at any time (a NEW stream
+ *     that reuses the handle value of a destroyed one takes over its entry: bfsm_synchronize then covers the new
+ *     stream's work; the destroyed stream's work completes under hipStreamDestroy's own rules).
  *   - functions never throw and never exit: they return BFSM_OK or an error code, and bfsm_last_error() returns a
  *     human-readable message (the reference prints and std::exit()s, CUDABoltzmannOperator.hpp:20-38; the C++
  *     wrapper restores that behaviour).
@@ -69,7 +73,7 @@ enum {
      * lx = 0 .. N/2 are computed and stored, the rest is rebuilt by conjugation plus exact rank-one Nyquist terms
      * (the r2c / c2r saving the reference lists as future work, CUDABoltzmannOperator.cu:36). */
     BFSM_FLAG_HERMITIAN = 4,
-    /* N = 16 only: do not use the whole-direction kernels (a direction kept in one workgroup's LDS, three launches
+    /* N = 16 only: do not use the whole-direction kernels (a direction kept in one workgroup's LDS, two launches
      * per evaluation) for single evaluations; the plane-tile pipeline of the larger grids is used instead.  Same
      * results up to rounding order; for comparisons and tests. */
     BFSM_FLAG_NO_SMALL_PATH = 8

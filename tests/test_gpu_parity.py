@@ -436,6 +436,111 @@ def test_cpp_multi_gpu_driver_on_one_device(torch_cuda):
         for k in ("L1", "L2", "Linf"):
             assert got[k] == pytest.approx(row[k], rel=6e-9), (k, got, extra)     # 9 printed digits
             assert re.fullmatch(r"\d\.\d{8}e[-+]\d\d", re.search(k + r" error: (\S+)", out.stdout).group(1))
+    # BASELINE config 5's form of the driver (single precision, its N = 128 grid; one radial node here), chunked, an explicit
+    # device list, the collectives forced on, per-device counters: the BKW collision term is reproduced to fp32 rounding
+    # (the spectral method is converged at N = 128: tools/fp32_accuracy.py)
+    out = subprocess.run([exe, "--Nv", "128", "--Ngl", "2", "--Ns", "192", "-t", "2", "--devices", "0", "--precision", "32",
+                          "--chunk", "100", "--force-rccl", "--counters", "--design-dir", os.path.join(pkg, "data", "sph_design")],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "precision = 32" in out.stdout and re.search(r"device 0: directions 384, chunks 4 x 96, kernels \S+ ms", out.stdout), out.stdout
+    assert '"precision": 32' in out.stdout
+    l2_32 = float(re.search(r"L2 error: (\S+)", out.stdout).group(1))
+    out = subprocess.run([exe, "--Nv", "128", "--Ngl", "2", "--Ns", "192", "-t", "1", "--gpus", "1",
+                          "--design-dir", os.path.join(pkg, "data", "sph_design")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    l2_64 = float(re.search(r"L2 error: (\S+)", out.stdout).group(1))
+    assert l2_32 < 1e-5 and abs(l2_32 - l2_64) < 1e-6, (l2_32, l2_64)      # two radial nodes: a quadrature error both share
+    # --input random and bad flags
+    out = subprocess.run([exe, "--Nv", "32", "--Ngl", "4", "--Ns", "12", "-t", "1", "--input", "random",
+                          "--design-dir", os.path.join(pkg, "data", "sph_design")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "sum |Q| =" in out.stdout
+    for bad in (["--devices", "0,0"], ["--devices", "7,x"], ["--precision", "16"], ["--gpus", "2", "--devices", "0"]):
+        out = subprocess.run([exe, "--Nv", "32", "--Ngl", "4", "--Ns", "12"] + bad, capture_output=True, text=True, timeout=120)
+        assert out.returncode != 0 and "error:" in out.stderr, bad
+
+
+class _UserQuadrature:
+    """A caller's own SphericalQuadrature (Quadratures/AbstractSphericalQuadratures.hpp:21-42): 13 nodes -- the 12-point
+    design rotated by a generic rotation plus one more node -- with unequal weights: no antipodal structure, no
+    permutation symmetry, an odd count."""
+
+    def __init__(self, oracle):
+        x, y, z, _ = oracle.spherical_design(12)
+        a, b, c = 0.37, 1.13, -0.61                          # Euler angles of a generic rotation
+        ca, sa, cb, sb, cc, sc = np.cos(a), np.sin(a), np.cos(b), np.sin(b), np.cos(c), np.sin(c)
+        R = np.array([[ca, -sa, 0], [sa, ca, 0], [0, 0, 1]]) @ np.array([[cb, 0, sb], [0, 1, 0], [-sb, 0, cb]]) @ \
+            np.array([[1, 0, 0], [0, cc, -sc], [0, sc, cc]])
+        pts = np.vstack([(R @ np.vstack([x, y, z])).T, [[0.6, -0.48, 0.64]]])
+        self._x, self._y, self._z = (np.ascontiguousarray(pts[:, k]) for k in range(3))
+        w = np.linspace(0.8, 1.3, 13)
+        self._w = w * (4 * np.pi / w.sum())
+
+    def getx(self): return self._x
+    def gety(self): return self._y
+    def getz(self): return self._z
+    def getWeights(self): return self._w
+    def getNumberOfPoints(self): return 13
+    def as_tuple(self): return (self._x, self._y, self._z, self._w)
+
+
+@pytest.mark.parametrize("mode", ["faithful", "exact", "hermitian"])
+@pytest.mark.parametrize("nv,n_gl", [(32, 3), (64, 2)])
+def test_user_supplied_quadrature_through_the_c_abi(torch_cuda, oracle, nv, n_gl, mode):
+    """The C-ABI takes arbitrary sx / sy / sz / sph_wts arrays like the reference's abstract SphericalQuadrature; every other
+    GPU case uses a shipped symmetric design with equal weights.  Here: 13 rotated, non-antipodal nodes with unequal weights,
+    whole field on the perturbed input against the oracle, faithful and with the exact-reduction flags (nothing can be
+    merged: antipodal_merged == 0, only the linearity part applies), plus a pair of direction shards."""
+    import bfsm
+    torch = torch_cuda
+    c = bfsm.reference_constants()
+    sph = _UserQuadrature(oracle)
+    f_h = bfsm.perturbed_input(bfsm.bkw_solution(nv)[0])
+    ref = oracle.collide(f_h, oracle.gauss_legendre(n_gl, 0.0, c["R"]), sph.as_tuple(), c["gamma"], c["b_gamma"], c["L"])
+
+    def make(shard=None):
+        op = bfsm.HIPBoltzmannOperator(bfsm.GaussLegendreQuadrature(n_gl, 0.0, c["R"]), sph, nv, nv, nv, c["gamma"], c["b_gamma"], c["L"])
+        op.setExactReductions(mode != "faithful", hermitian=(mode == "hermitian"))
+        if shard:
+            op.setDirectionShard(*shard)
+        op.initialize()
+        return op
+
+    op = make()
+    cn = op.counters()
+    assert cn.antipodal_merged == 0 and cn.exact_reductions == (0 if mode == "faithful" else 1) and cn.n_dirs == 13 * n_gl
+    got = _collide(torch, op, f_h)
+    op.destroy()
+    assert np.abs(got - ref).max() <= TOL64 * np.abs(ref).max()
+    f = torch.from_numpy(f_h).cuda()
+    total = 0
+    for r in range(2):                                       # shards that cut through a radial node's 13 directions
+        op = make(bfsm.shard_range(13 * n_gl, r, 2))
+        Q = torch.empty_like(f)
+        op.collidePartial(Q, f, r == 0)
+        torch.cuda.synchronize()
+        total = total + Q.cpu().numpy()
+        op.destroy()
+    assert np.abs(total - ref).max() <= TOL64 * np.abs(ref).max()
+
+
+def test_cpp_multi_gpu_operator_batches_and_input_stream(torch_cuda, tmp_path):
+    """tests/host/test_multigpu_hip.cpp: BoltzmannOperator<HIP_MultiGPU_Backend> on real HIP + RCCL (collectives forced on;
+    two devices where the box has them): a batch equals its single evaluations bitwise, f produced on a non-blocking
+    stream is waited for through setInputStream(), counters() per device, setMaxChunk() reaches the devices."""
+    import subprocess
+    root = os.path.dirname(HERE)
+    pkg = os.path.join(root, "boltzmann-fourier-spectral-method_amd")
+    exe = str(tmp_path / "test_multigpu_hip")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O1", "-std=c++17", "--offload-arch=gfx950", "-I", os.path.join(pkg, "host"),
+                           "-I", os.path.join(root, "include"), "-x", "hip", os.path.join(root, "tests", "host", "test_multigpu_hip.cpp"),
+                           os.path.join(pkg, "host", "HIPMultiGPUBoltzmannOperator.cpp"),
+                           os.path.join(pkg, "host", "HIPBoltzmannOperator.cpp"), os.path.join(pkg, "host", "Quadratures", "SphericalDesign.cpp"),
+                           "-L" + pkg, "-lbfsm_hip", "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib",
+                           "-o", exe])
+    out = subprocess.run([exe, os.path.join(pkg, "data", "sph_design")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "multi-GPU operator checks passed" in out.stdout
 
 
 @pytest.mark.parametrize("nv,n_gl,n_sph", [(16, 8, 32), (32, 8, 48), (64, 2, 12)])
@@ -484,6 +589,8 @@ def test_bench_two_ranks_rehearsal(torch_cuda):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "strong"
     assert d["config"]["directions_per_gpu"] == 192 and d["cpu_baseline"] is None
+    assert d["config"]["directions_per_gpu_min"] == 192 and d["config"]["directions_per_gpu_max"] == 192
+    assert d["config"]["rank_devices"] == [0, 0]          # the gloo rehearsal shares device 0; RCCL runs refuse that
     assert d["config"]["collective"]["ranks"] == 2 and d["config"]["collective_overlap"] is False
     assert d["blocking_call"]["value"] > 0 and d["overlapped"]["value"] > 0
     assert d["exact_reductions"]["value"] > 0
@@ -893,7 +1000,7 @@ def test_cpp_driver_on_a_size_with_factor_three(torch_cuda):
 @pytest.mark.parametrize("mode", ["faithful", "exact", "hermitian"])
 @pytest.mark.parametrize("n_gl,n_sph,prec", [(8, 32, 64), (40, 12, 64), (3, 6, 64), (8, 32, 32)])
 def test_n16_whole_direction_kernels_and_tile_pipeline_agree_with_oracle(torch_cuda, oracle, n_gl, n_sph, prec, mode):
-    """N = 16 single evaluations run on the whole-direction kernels (three launches); BFSM_FLAG_NO_SMALL_PATH sends the
+    """N = 16 single evaluations run on the whole-direction kernels (two launches); BFSM_FLAG_NO_SMALL_PATH sends the
     same call through the plane-tile pipeline.  Both against the oracle, all three modes, plus a shard without loss."""
     import bfsm
     torch = torch_cuda
@@ -1066,7 +1173,8 @@ def test_batch_of_one_equals_a_single_evaluation_bitwise(torch_cuda):
 
 @pytest.mark.parametrize("mode", ["faithful", "exact", "hermitian"])
 @pytest.mark.parametrize("nv,n_gl,n_sph,prec", [(48, 4, 12, 64), (96, 2, 12, 64), (48, 4, 12, 32), (96, 2, 12, 32),
-                                                (80, 2, 12, 64), (80, 2, 12, 32), (24, 4, 12, 64), (40, 4, 12, 64)])
+                                                (80, 2, 12, 64), (80, 2, 12, 32), (24, 4, 12, 64), (40, 4, 12, 64),
+                                                (24, 4, 12, 32), (40, 4, 12, 32)])
 def test_fused_radix3_sizes_match_oracle(torch_cuda, oracle, nv, n_gl, n_sph, prec, mode):
     """N = 48, 96 (prime-factor 4 x 3 / 8 x 3 register transforms, 4 threads per line), N = 80 (4 x 5) and N = 24 (two
     threads per line) on the fused three-kernel pipeline: whole field on the perturbed input against the oracle, all

@@ -51,3 +51,19 @@ def test_multigpu_operator_choreography_with_p_gt_1(tmp_path, sanitizer):
     out = subprocess.run([exe, os.path.join(PKG, "data", "sph_design")], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "multi-GPU choreography checks passed" in out.stdout and "ThreadSanitizer" not in out.stderr
+
+
+@pytest.mark.parametrize("mode,needle", [("fail-broadcast", "injected broadcast failure"), ("fail-reduce", "injected reduce failure"),
+                                         ("fail-shard", "injected shard failure"), ("stall", "did not finish within")])
+def test_multigpu_operator_fails_loudly_instead_of_hanging(tmp_path, mode, needle):
+    """A collective that fails on one rank, a device shard that fails, and a rank that never joins the reduce: the
+    process ends with the message on stderr and a non-zero status within seconds (device-thread failures through _Exit,
+    the stalled rank through the watchdog of the blocking call) -- the caller never dead-locks in compute()."""
+    exe = str(tmp_path / "test_multigpu_choreography")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-pthread", "-I", os.path.join(PKG, "host"), "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "host", "test_multigpu_choreography.cpp"),
+                           os.path.join(PKG, "host", "Quadratures", "SphericalDesign.cpp"), "-o", exe])
+    out = subprocess.run([exe, os.path.join(PKG, "data", "sph_design"), mode], capture_output=True, text=True, timeout=60)
+    assert out.returncode != 0, out.stdout + out.stderr
+    assert needle in out.stderr and "HIP backend error in computeCollision" in out.stderr, out.stderr
+    assert "returned although" not in out.stdout
