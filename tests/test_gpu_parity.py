@@ -437,8 +437,8 @@ def test_cpp_multi_gpu_driver_on_one_device(torch_cuda):
             assert got[k] == pytest.approx(row[k], rel=6e-9), (k, got, extra)     # 9 printed digits
             assert re.fullmatch(r"\d\.\d{8}e[-+]\d\d", re.search(k + r" error: (\S+)", out.stdout).group(1))
     # BASELINE config 5's form of the driver (single precision, its N = 128 grid; one radial node here), chunked, an explicit
-    # device list, the collectives forced on, per-device counters: the BKW collision term is reproduced to fp32 rounding
-    # (the spectral method is converged at N = 128: tools/fp32_accuracy.py)
+    # device list, the collectives forced on, per-device counters: the error norm against the analytic
+    # BKW collision term equals the fp64 run's to fp32 rounding
     out = subprocess.run([exe, "--Nv", "128", "--Ngl", "2", "--Ns", "192", "-t", "2", "--devices", "0", "--precision", "32",
                           "--chunk", "100", "--force-rccl", "--counters", "--design-dir", os.path.join(pkg, "data", "sph_design")],
                          capture_output=True, text=True, timeout=600)
@@ -450,7 +450,8 @@ def test_cpp_multi_gpu_driver_on_one_device(torch_cuda):
                           "--design-dir", os.path.join(pkg, "data", "sph_design")], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     l2_64 = float(re.search(r"L2 error: (\S+)", out.stdout).group(1))
-    assert l2_32 < 1e-5 and abs(l2_32 - l2_64) < 1e-6, (l2_32, l2_64)      # two radial nodes: a quadrature error both share
+    # two radial nodes: a quadrature error of a few per cent that both precisions share to fp32 rounding
+    assert abs(l2_32 - l2_64) <= 5e-6 * l2_64, (l2_32, l2_64)
     # --input random and bad flags
     out = subprocess.run([exe, "--Nv", "32", "--Ngl", "4", "--Ns", "12", "-t", "1", "--input", "random",
                           "--design-dir", os.path.join(pkg, "data", "sph_design")], capture_output=True, text=True, timeout=300)
