@@ -773,6 +773,21 @@ template <int N, typename T> constexpr bool ab_interleaved() {
 #endif
 }
 
+// A/B build (tools: -DBFSM_KA_XLANE): the LAST line pass of each KA tile at N = 128 fp32 as a wave-private pass.  The
+// transposing read hands every wave 8 columns with the 8 threads of a line at lane bits 3..5, the exchange between the two
+// register steps is done across lanes (v_permlane32_swap, v_permlane16_swap, DPP row_ror:8: DevCtx::xlane_transpose8) instead
+// of through LDS, and the pair loop has 8 barriers instead of 12, none of them next to the global-store burst.  The
+// inter-step twiddles are per-lane data then (read from a small LDS table); tile rows get a stride of N + 4 elements so that
+// the new transposing read is bank-conflict free.  Measured: DESIGN.md 7.1 / profiles/r04_ka_xlane_lastpass_ab.txt.
+template <int N, typename T> constexpr bool ka_xlane() {
+#ifdef BFSM_KA_XLANE
+    return sizeof(T) == 4 && N == 128 && ab_interleaved<N, T>();
+#else
+    return false;
+#endif
+}
+template <int N, typename T> constexpr size_t ka_xlane_lds_bytes() { return ((size_t)N * (N + 4) + 8 * 17) * sizeof(cx<T>); }
+
 // (Measured and rejected at N = 128 fp32, profiles/r03_ka_wide32_ab.txt, code in commit ab65758: 32 points per thread, 512 threads per
 // tile, the 2-D tile transform in three register passes -- z: 32 x 4, y: 8 x 16 -- with two exchanges and 8 barriers per
 // direction instead of three and 12.  Correct, 227 VGPRs, 6.40 against 5.35 ms: half the waves hide less than the exchanges save.)
@@ -822,7 +837,8 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
         //    wr A, dft(B) | rd A | wr B, step2(A), store A | rd B | step2(B), store B
         // ("|" = barrier; 12 per direction instead of 14).  The phase factors are formed once per point and used for both
         // signs (the two tiles are live together here anyway).  Measured against the sequential form: see DESIGN.md 7.1.
-        constexpr int Q = Wg<N>::Q, LS = Wg<N>::LS;
+        constexpr bool XL = PAIRS && ka_xlane<N, T>();
+        constexpr int Q = Wg<N>::Q, LS = XL ? N + 4 : Wg<N>::LS;
         unsigned pl = (unsigned)p * (unsigned)sizeof(cx<T>);   // this lane's byte offset inside a row
         // Exchange addresses.  A tile beyond 64 KiB (N = 128) does not fit the 16-bit immediate offset of the LDS
         // instructions; left to itself the compiler then keeps one address register PER ROW of the upper half (17 VGPRs of
@@ -917,6 +933,86 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
         constexpr bool ROWU = Wg<N>::ROW % 64 == 0;
         cx<T> py = {(T)0, (T)0};
         if (d_begin < d_end) py = ctx.template ld_at<ROWU>(prm.phy + (size_t)(prm.dir0 + d_begin) * N, (unsigned)p * (unsigned)sizeof(cx<T>));
+        if constexpr (XL) {
+            // ---- cross-lane form of the last line pass (see ka_xlane) -------------------------------------------------
+            // second thread mapping, used behind the transposing exchange: wave w takes the columns z = 8 w + (lane & 7), the
+            // 8 threads of a line sit at lane bits 3..5 (u2 = lane >> 3)
+            const int lane = tid & 63, u2 = lane >> 3, z2 = (tid >> 6) * 8 + (lane & 7);
+            cx<T>* const twl = lds + N * LS;                       // [u2][q][uu] inter-step twiddles, rows of 17 (banks)
+            if (tid < 8 * 16) {
+                const int tu = tid >> 4, tq = (tid >> 3) & 1, tuu = tid & 7;
+                twl[tu * 17 + tq * 8 + tuu] = ctx.ldc(prm.tw + ((tuu * (tu + TT * tq)) % N));
+            }
+            cx<T>* const trd = lds + z2 * LS + u2;                 // transposing read: row z2, columns u2 + 8 m
+            const cx<T>* const tw2 = twl + u2 * 17;
+            auto xr_tr2 = [&](cx<T>* v) {
+#pragma unroll
+                for (int m = 0; m < E; ++m) v[m] = ctx.lds_ld(trd + TT * m);
+            };
+            // radix-T step behind the cross-lane exchange; results stay in w2[q T + k2] = row y = u2 + T (q + Q k2)
+            auto step2_x = [&](cx<T>* w2) {
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    cx<T> w[TT];
+                    w[0] = {(T)1, (T)0};
+#pragma unroll
+                    for (int uu = 1; uu < TT; ++uu) w[uu] = ctx.lds_ld(tw2 + q * TT + uu);
+                    SmallDftTw<TT, +1, T, true>::run(w2 + q * TT, w);
+                }
+            };
+            ctx.drain_loads();
+            for (int d = d_begin; d < d_end; ++d) {
+                const size_t b = (size_t)(prm.dir0 + d);
+                const cx<T> c0 = cmul(ctx.ldc(prm.phx + b * N + lxi), py);
+                pl = ctx.lane_off((unsigned)p * (unsigned)sizeof(cx<T>));
+                if (d + 1 < d_end) py = ctx.template ld_at<ROWU>(prm.phy + (size_t)(prm.dir0 + d + 1) * N, pl);
+                cx<T> va[E], vb[E], wa[E], wb[E];
+#pragma unroll
+                for (int m = 0; m < E; ++m) {
+                    const cx<T> ph = cmul(c0, ctx.ldc(prm.phz + b * N + u + TT * m));
+                    va[m] = cmul(fh[m], ph);
+                    vb[m] = cmulc(fh[m], ph);
+                }
+                SmallDft<E, +1, T>::run(va);
+                BFSM_TSYNC(0);                                        // the previous direction's transposed reads are done
+                xw_line(va);
+                ctx.sched_fence();
+                SmallDft<E, +1, T>::run(vb);
+                BFSM_TSYNC(1); xr_line(wa); BFSM_TSYNC(2);
+                xw_line(vb);
+                ctx.sched_fence();
+                fft_line_step2<N, +1, T>(va, wa, twr, ctx);
+                BFSM_TSYNC(3); xr_line(wb); BFSM_TSYNC(4);
+                xw_tr(va);
+                ctx.sched_fence();
+                fft_line_step2<N, +1, T>(vb, wb, twr, ctx);
+                BFSM_TSYNC(5); xr_tr2(va); BFSM_TSYNC(6);
+                xw_tr(vb);
+                ctx.sched_fence();
+                SmallDft<E, +1, T>::run(va);
+                ctx.xlane_transpose8(va);                          // va[q T + uu] = (thread uu's va[u2 + T q])
+                step2_x(va);
+                BFSM_TSYNC(7); xr_tr2(vb);
+                ctx.sched_fence();
+                SmallDft<E, +1, T>::run(vb);
+                ctx.xlane_transpose8(vb);
+                // B's radix-T step and the pair stores: row pointer uniform, lane offset (u2 N + z2) pairs
+                cx<T>* dst = prm.a1 + 2 * (bz * prm.a_bstride + ((size_t)d * prm.planes + lxi) * N * N);
+                const unsigned pl2 = ctx.lane_off((unsigned)(u2 * N + z2) * (unsigned)(2 * sizeof(cx<T>)));
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    cx<T> w[TT];
+                    w[0] = {(T)1, (T)0};
+#pragma unroll
+                    for (int uu = 1; uu < TT; ++uu) w[uu] = ctx.lds_ld(tw2 + q * TT + uu);
+                    SmallDftTw<TT, +1, T, true>::run(vb + q * TT, w);
+#pragma unroll
+                    for (int k2 = 0; k2 < TT; ++k2)   // row y = u2 + T (q + Q k2), z = z2
+                        ctx.template st_stream_pair_at<true>(dst + 2 * (size_t)(TT * (q + Q * k2)) * N, pl2, va[q * TT + k2], vb[q * TT + k2]);
+                    ctx.sched_fence();
+                }
+            }
+        } else {
         ctx.drain_loads();     // no per-iteration vmcnt(0) (= store drain) at the loop header, see DevCtx::drain_loads
         for (int d = d_begin; d < d_end; ++d) {
             const size_t b = (size_t)(prm.dir0 + d);
@@ -984,6 +1080,7 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
             else step2_store(prm.a2, d, wb);
             if (warming) { ctx.keep_alive(warm); ctx.keep_alive(warm2); }
         }
+        }   // !XL
 #ifdef BFSM_KA_BARRIER_TIMES
 #pragma unroll
         for (int k = 0; k < 13; ++k) ctx.dbg_add(k, tbar[k]);
@@ -1364,12 +1461,15 @@ BFSM_HD void hermitian_lines_load(cx<T>* a, cx<T>* b, const cx<T>* A1, const cx<
         ctx.lds_st(hb + (u + TT * m) * LS + p, b[m]);
     }
     ctx.sync();
+    // mirror rows: row m is the conjugate of the stored row q = N - (u + T m) = (T - u) + T (E - 1 - m), 1 <= q < N/2.
+    // ONE address register (the row of m = E - 1, opaque to the optimiser) + non-negative immediates: left to itself the
+    // compiler kept one register per row and array -- 8 of them spilled at the 128-VGPR cap of N = 64 in double precision
+    const cx<T>* const mlo = lds + ctx.opaque_v((TT - u) * LS + p);
 #pragma unroll
     for (int m = MS; m < E; ++m) {
         if (m > MS || u != 0) {
-            const int q = N - (u + TT * m);        // stored row whose conjugate this row is, 1 <= q < N/2
-            a[m] = ctx.lds_ld(ha + q * LS + p);
-            b[m] = ctx.lds_ld(hb + q * LS + p);
+            a[m] = ctx.lds_ld(mlo + TT * (E - 1 - m) * LS);
+            b[m] = ctx.lds_ld(mlo + ((H + 1) + TT * (E - 1 - m)) * LS);
         }
     }
 }
@@ -1386,21 +1486,31 @@ BFSM_HD void hermitian_line_load1(cx<T>* a, const cx<T>* A1, int colrow, unsigne
 #pragma unroll
     for (int m = 0; m < MS; ++m) ctx.lds_st(lds + (u + TT * m) * LS + p, a[m]);
     ctx.sync();
+    const cx<T>* const mlo = lds + ctx.opaque_v((TT - u) * LS + p);     // see hermitian_lines_load
 #pragma unroll
     for (int m = MS; m < E; ++m)
-        if (m > MS || u != 0) a[m] = ctx.lds_ld(lds + (N - (u + TT * m)) * LS + p);
+        if (m > MS || u != 0) a[m] = ctx.lds_ld(mlo + TT * (E - 1 - m) * LS);
 }
 
 template <int N, typename T, class Ctx>
 BFSM_HD void hermitian_line_fix(cx<T>* v, const cx<T>* R, int y, int z, int u, Ctx& ctx) {
     constexpr int E = Wg<N>::E, TT = Wg<N>::T, NQ = N / 2 - 1, H = N / 2, MS = E / 2;
     const T sy = (y & 1) ? (T)-1 : (T)1, sz = (z & 1) ? (T)-1 : (T)1;
+    const unsigned zoff = ctx.lane_off((unsigned)z * (unsigned)sizeof(cx<T>));
+    unsigned yoff = 0;
+    if constexpr (Wg<N>::NPL > N && Wg<N>::LROW % 64 == 0) yoff = ctx.lane_off((unsigned)y * (unsigned)sizeof(cx<T>));
 #pragma unroll
     for (int m = MS; m < E; ++m) {
         const bool mir = (m > MS) || u != 0;
         const int j = mir ? u + TT * m - (H + 1) : 0;
-        const cx<T> r1 = R[(size_t)j * N + z];
-        const cx<T> r2 = ctx.ldc(R + (size_t)(NQ + j) * N + y);     // (j, y) are wave-uniform for N >= 64
+        // wave-uniform row + one lane offset (scalar-base load: no 64-bit address per row held in VGPRs across the
+        // direction loop -- they were what the kernel spilled at the 128-VGPR cap)
+        const int ju = ctx.uniform(j, Wg<N>::LROW);              // (wave-uniform wherever a row of lanes is whole waves)
+        const cx<T> r1 = ctx.template ld_at<Wg<N>::LROW % 64 == 0>(R + (size_t)ju * N, zoff);
+        cx<T> r2;
+        if constexpr (Wg<N>::NPL > N && Wg<N>::LROW % 64 == 0)       // N = 32: y differs inside a wave, the row does not
+            r2 = ctx.template ld_at<true>(R + (size_t)(NQ + ju) * N, yoff);
+        else r2 = ctx.ldc(R + (size_t)(NQ + ju) * N + y);           // (j, y) are wave-uniform for N >= 64
         const T k = mir ? (T)1 : (T)0, c = mir ? (T)-1 : (T)1;
         v[m] = {v[m].x + k * (sy * r1.x + sz * r2.x), c * v[m].y + k * (sy * r1.y + sz * r2.y)};
     }
@@ -1437,7 +1547,12 @@ BFSM_HD void body_gain_line_acc_h(const GainLineAccHParams<T>& prm, Ctx& ctx) {
         const size_t abase = (size_t)ctx.bz() * prm.a_bstride + (size_t)d * NH * N * N;
         const cx<T>* R = prm.r + (size_t)ctx.bz() * prm.r_bstride + (size_t)d * 4 * NQ * N;
         cx<T> a[E], b[E];
-        if constexpr (N >= 128) {      // 16 points per thread: one line at a time keeps the kernel inside 128 VGPRs
+#ifdef BFSM_ACCH_ONE_LINE          // A/B builds (tools only): the one-line-at-a-time ordering at every size
+        constexpr bool ONE_LINE = true;
+#else
+        constexpr bool ONE_LINE = N >= 128;
+#endif
+        if constexpr (ONE_LINE) {      // 16 points per thread: one line at a time keeps the kernel inside 128 VGPRs
             hermitian_line_load1<N, T>(a, prm.a1 + abase, colrow, pl, p, u, lds, ctx);      // (two arrays in this mode)
             hermitian_line_fix<N, T>(a, R, y, z, u, ctx);
             fft_line_np<N, NPL, +1, T>(a, lds, p, u, twr, ctx);
@@ -1461,9 +1576,13 @@ BFSM_HD void body_gain_line_acc_h(const GainLineAccHParams<T>& prm, Ctx& ctx) {
     }
     fft_line_np<N, NPL, -1, T>(acc, lds, p, u, twr, ctx);
     const size_t obase = (size_t)ctx.bz() * prm.pseg_bstride + (size_t)(prm.seg0 + gby) * N * N * N + colrow;
+    // the lane offset of the final stores is re-derived from the thread id (not kept in a register across the direction
+    // loop: at the 128-VGPR cap of N = 64 in double precision that one value went to scratch)
+    const int pr3 = ctx.opaque_v(ctx.tid()) % Wg<N>::LROW;
+    const unsigned pl3 = (unsigned)((Wg<N>::LROW == NPL || pr3 < NPL) ? pr3 : pr3 - (Wg<N>::LROW - NPL)) * (unsigned)sizeof(cx<T>);
 #pragma unroll
     for (int m = 0; m < E; ++m)
-        ctx.template st_at<Wg<N>::LROW % 64 == 0>(prm.pseg + obase + (size_t)(u + TT * m) * N * N, pl, acc[m]);
+        ctx.template st_at<Wg<N>::LROW % 64 == 0>(prm.pseg + obase + (size_t)(u + TT * m) * N * N, pl3, acc[m]);
 }
 
 // KC.  grid = (N planes x, segments of the chunk).  (y,z) part of the forward transform + the direction sum of

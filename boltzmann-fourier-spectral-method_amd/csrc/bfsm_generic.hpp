@@ -180,7 +180,10 @@ BFSM_HD void gen_pass(const cx<T>* src, cx<T>* dst, const cx<T>* tw, int n, int 
 // Batched 1-D transform along one axis.  grid = (blocks of GEN_C lines, batch).  Workgroup: GEN_THREADS threads, LDS =
 // two buffers of n x (GEN_C + 1) complex.  A "line" is the set of n points along the transformed axis; consecutive
 // lines are consecutive in z (axes x, y) or consecutive (x, y) pairs (axis z).
-template <typename T, class Ctx>
+// BIG: the instantiation that also carries the table-driven radix-7 / 11 / 13 butterflies (13 complex inputs + 13 outputs
+// in registers: 256 VGPRs and a kilobyte of scratch per lane in double precision).  Axes whose factors are 2, 3, 5 only --
+// nearly every box -- run the instantiation without them (round 4; GK::Fft / GK::FftBig).
+template <typename T, bool BIG, class Ctx>
 BFSM_HD void body_gen_fft(const GenFftParams<T>& prm, Ctx& ctx) {
     const int nx = prm.nx, ny = prm.ny, nz = prm.nz;
     const int axis = prm.axis;
@@ -259,9 +262,11 @@ BFSM_HD void body_gen_fft(const GenFftParams<T>& prm, Ctx& ctx) {
         else if (R == 3) gen_pass<3, false, T>(src, dst, prm.tw, n, ns, prm.sign, ctx);
         else if (R == 5 && p2) gen_pass<5, true, T>(src, dst, prm.tw, n, ns, prm.sign, ctx);
         else if (R == 5) gen_pass<5, false, T>(src, dst, prm.tw, n, ns, prm.sign, ctx);
-        else if (R == 7) gen_pass<7, false, T>(src, dst, prm.tw, n, ns, prm.sign, ctx);
-        else if (R == 11) gen_pass<11, false, T>(src, dst, prm.tw, n, ns, prm.sign, ctx);
-        else gen_pass<13, false, T>(src, dst, prm.tw, n, ns, prm.sign, ctx);
+        else if constexpr (BIG) {
+            if (R == 7) gen_pass<7, false, T>(src, dst, prm.tw, n, ns, prm.sign, ctx);
+            else if (R == 11) gen_pass<11, false, T>(src, dst, prm.tw, n, ns, prm.sign, ctx);
+            else gen_pass<13, false, T>(src, dst, prm.tw, n, ns, prm.sign, ctx);
+        }
         ns *= R;
         ctx.sync();
         cx<T>* t = src; src = dst; dst = t;
@@ -300,7 +305,7 @@ BFSM_HD void body_gen_combine(const GenCombineParams<T>& prm, Ctx& ctx) {
     prm.Q[idx] = q;
 }
 
-enum class GK { Fft, Acc, Combine };
+enum class GK { Fft, Acc, Combine, FftBig };   // FftBig: Fft + the radix-7 / 11 / 13 passes
 
 inline bool gen_factor(int n, std::vector<int>& radix) {
     radix.clear();
@@ -480,7 +485,10 @@ struct GenericPipeline {
         p.mode = mode; p.phx = phx; p.phy = phy; p.phz = phz; p.dir0 = dir0; p.beta2 = beta2;
         p.in_bstride = in_bstride; p.out_bstride = out_bstride;
         const size_t lds = (size_t)2 * n * (C + 1) * sizeof(cx<T>);
-        be->template launch_gen<GK::Fft, T>((ncols + C - 1) / C, batch, GEN_THREADS, lds, p);
+        bool big = false;
+        for (int r : radix[axis]) big = big || r > 5;
+        if (big) be->template launch_gen<GK::FftBig, T>((ncols + C - 1) / C, batch, GEN_THREADS, lds, p);
+        else be->template launch_gen<GK::Fft, T>((ncols + C - 1) / C, batch, GEN_THREADS, lds, p);
     }
 
     // f_hat = FFT(f), then the gain term of this shard into qhat   (CUDABoltzmannOperator.cu:131-191)

@@ -222,6 +222,40 @@ struct DevCtx {
         __builtin_nontemporal_store(r, (gvec)(g + byte_off));
 #pragma clang diagnostic pop
     }
+    // Cross-lane exchange of a distributed line transform whose 8 threads sit at lane bits 3..5 of ONE wave (A/B build
+    // BFSM_KA_XLANE): in v[k1] (k1 < 16) of thread u = lane >> 3; out v[q * 8 + uu] = (thread uu's v[u + 8 q]) -- two 8 x 8
+    // register <-> lane transposes, one exchange step per lane bit: v_permlane32_swap (bit 5), v_permlane16_swap (bit 4),
+    // DPP row_ror:8 + select (bit 3).  No LDS, no barrier.  The sequence validated in tools/micro/xlane_exchange.hip (inline
+    // assembly: the swap builtins were miscompiled in this use; s_nop 1 = the wait states behind a VALU write of an operand).
+    template <int BIT>
+    __device__ __forceinline__ void xstep(float& a, float& b, bool bit_set) const {
+        if constexpr (BIT == 32) {
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+        } else if constexpr (BIT == 16) {
+            asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+        } else {
+            float pa, pb;
+            asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %1, %3 row_ror:8 row_mask:0xf bank_mask:0xf"
+                         : "=&v"(pa), "=&v"(pb) : "v"(a), "v"(b));
+            const float na = bit_set ? pb : a, nb = bit_set ? b : pa;
+            a = na;
+            b = nb;
+        }
+    }
+    __device__ __forceinline__ void xlane_transpose8(cx<float>* v) const {
+        const int lane = (int)threadIdx.x & 63;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            cx<float>* r = v + 8 * q;          // block k1 = 8 q + j: transpose register index j <-> thread index u
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (!(j & 4)) { xstep<32>(r[j].x, r[j | 4].x, lane & 32); xstep<32>(r[j].y, r[j | 4].y, lane & 32); }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (!(j & 2)) { xstep<16>(r[j].x, r[j | 2].x, lane & 16); xstep<16>(r[j].y, r[j | 2].y, lane & 16); }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (!(j & 1)) { xstep<8>(r[j].x, r[j | 1].x, lane & 8); xstep<8>(r[j].y, r[j | 1].y, lane & 8); }
+        }
+    }
+    __device__ __forceinline__ void xlane_transpose8(cx<double>*) const {}    // (no double-precision geometry uses it)
     // cacheable (plain) variants of the row + lane-offset accessors
     template <bool UNI, class T>
     __device__ __forceinline__ cx<T> ld_at(const cx<T>* row, unsigned byte_off) const {
@@ -302,6 +336,7 @@ constexpr int kernel_threads() {
 template <K kind, int N, typename T>
 constexpr size_t kernel_lds_bytes() {
     if (kind == K::GainInv && pair_tile<N>()) return pair_lds_bytes<N, T>();
+    if (kind == K::GainInv && ka_xlane<N, T>()) return ka_xlane_lds_bytes<N, T>();
     if (kind == K::GainFwd) return kc_lds_bytes<N, T>();
     if (kind == K::GainInvNyq) return gain_inv_lds_bytes<N, T>();
     return kind == K::Reduce ? 0 : (is_line_kind(kind) ? line_lds_bytes<N, T>() : tile_lds_bytes<N, T>());
@@ -349,7 +384,8 @@ template <GK kind, typename T, class P>
 __global__ void __launch_bounds__(GEN_THREADS) bfsm_gen_kernel(const P prm) {
     extern __shared__ __align__(16) unsigned char bfsm_smem[];
     DevCtx ctx{bfsm_smem};
-    if constexpr (kind == GK::Fft) body_gen_fft<T>(prm, ctx);
+    if constexpr (kind == GK::Fft) body_gen_fft<T, false>(prm, ctx);
+    else if constexpr (kind == GK::FftBig) body_gen_fft<T, true>(prm, ctx);
     else if constexpr (kind == GK::Acc) body_gen_acc<T>(prm, ctx);
     else if constexpr (kind == GK::Combine) body_gen_combine<T>(prm, ctx);
 }

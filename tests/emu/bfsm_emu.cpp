@@ -61,6 +61,8 @@ struct EmuCtx {
     template <bool UNI, class U> auto ld_real_at(const U* row, unsigned byte_off) const {
         return reinterpret_cast<const U*>(reinterpret_cast<const unsigned char*>(row) + byte_off)->x;
     }
+    // cross-lane exchange of DevCtx::xlane_transpose8, through a per-block staging buffer and two wave barriers
+    template <class U> void xlane_transpose8(U* v);
     void sync();       // workgroup barrier
     void sched_fence() const {}   // compiler scheduling hint on the device; nothing to do on the host
     void drain_loads() const {}   // wait-count hygiene on the device; nothing to do on the host
@@ -86,6 +88,7 @@ struct Sched {
     std::vector<char> state;
     int current = -1;
     bool deadlock = false;
+    std::vector<unsigned char> xbuf;     // staging of EmuCtx::xlane_transpose8
     void (*entry)(void*, EmuCtx&) = nullptr;
     void* arg = nullptr;
     std::vector<EmuCtx> ectx;
@@ -156,6 +159,17 @@ struct Sched {
     }
 };
 inline void EmuCtx::sync() { sched->yield(Sched::AT_BLOCK); }
+template <class U> void EmuCtx::xlane_transpose8(U* v) {
+    std::vector<unsigned char>& buf = sched->xbuf;
+    if (buf.size() < (size_t)nthreads_ * 16 * sizeof(U)) buf.resize((size_t)nthreads_ * 16 * sizeof(U));
+    U* b = reinterpret_cast<U*>(buf.data());
+    for (int k = 0; k < 16; ++k) b[(size_t)tid_ * 16 + k] = v[k];
+    sched->yield(Sched::AT_WAVE);
+    const int lane = tid_ & 63, u = lane >> 3, w0 = tid_ - lane + (lane & 7);
+    for (int q = 0; q < 2; ++q)
+        for (int uu = 0; uu < 8; ++uu) v[q * 8 + uu] = b[(size_t)(w0 + 8 * uu) * 16 + u + 8 * q];
+    sched->yield(Sched::AT_WAVE);
+}
 inline void EmuCtx::wave_sync() { sched->yield(Sched::AT_WAVE); }
 
 struct EmuBackend {
@@ -199,6 +213,7 @@ struct EmuBackend {
         const int threads = pair ? bfsm::pair_threads<N>() : kind == bfsm::K::Reduce ? 256
                             : (bfsm::is_line_kind(kind) ? bfsm::Wg<N>::LINE_THREADS : bfsm::Wg<N>::THREADS);
         smem.assign(pair ? bfsm::pair_lds_bytes<N, T>()
+                         : (kind == bfsm::K::GainInv && bfsm::ka_xlane<N, T>()) ? bfsm::ka_xlane_lds_bytes<N, T>()
                          : kind == bfsm::K::GainFwd ? bfsm::kc_lds_bytes<N, T>()
                          : kind == bfsm::K::GainInvNyq ? bfsm::gain_inv_lds_bytes<N, T>()
                          : (bfsm::is_line_kind(kind) ? bfsm::line_lds_bytes<N, T>() : bfsm::tile_lds_bytes<N, T>()), 0xCD);
@@ -231,7 +246,8 @@ struct EmuBackend {
     template <bfsm::GK kind, typename T, class P>
     static void body_gen(void* a, EmuCtx& ctx) {
         const P& prm = *static_cast<const P*>(a);
-        if constexpr (kind == bfsm::GK::Fft) bfsm::body_gen_fft<T>(prm, ctx);
+        if constexpr (kind == bfsm::GK::Fft) bfsm::body_gen_fft<T, false>(prm, ctx);
+    else if constexpr (kind == bfsm::GK::FftBig) bfsm::body_gen_fft<T, true>(prm, ctx);
         else if constexpr (kind == bfsm::GK::Acc) bfsm::body_gen_acc<T>(prm, ctx);
         else if constexpr (kind == bfsm::GK::Combine) bfsm::body_gen_combine<T>(prm, ctx);
     }

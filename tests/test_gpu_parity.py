@@ -415,6 +415,40 @@ def test_n128_fp64_matches_oracle(torch_cuda, oracle):
     assert np.abs(Qb[1].cpu().numpy() - 0.25 * ref).max() <= TOL64 * np.abs(ref).max()
 
 
+def test_ka_cross_lane_build_matches_oracle(torch_cuda, oracle, tmp_path):
+    """The cross-lane ("wavefront shuffle") form of KA's last line pass at N = 128 fp32 (csrc/bfsm_core.hpp ka_xlane,
+    DevCtx::xlane_transpose8: v_permlane32_swap / v_permlane16_swap / DPP row_ror) is a build option (-DBFSM_KA_XLANE):
+    measured 6 % slower than the LDS exchange in the kernel (profiles/r04_ka_xlane_lastpass_ab.txt), so it is not the
+    default -- but it stays correct: built here and run in a child process against the oracle."""
+    import subprocess
+    import sys
+    import bfsm
+    root = os.path.dirname(HERE)
+    pkg = os.path.join(root, "boltzmann-fourier-spectral-method_amd")
+    lib = str(tmp_path / "libbfsm_xlane.so")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wno-unused-function",
+                           "-fno-slp-vectorize", "-DBFSM_KA_XLANE", "-shared", "-o", lib, os.path.join(pkg, "csrc", "bfsm_hip.hip")])
+    nv, n_gl, n_sph = 128, 2, 12
+    f_h = bfsm.perturbed_input(bfsm.bkw_solution(nv)[0])
+    ref = _oracle(oracle, f_h, n_gl, n_sph)
+    np.save(tmp_path / "f.npy", f_h)
+    code = (
+        "import sys, numpy as np, torch\n"
+        f"sys.path.insert(0, {pkg!r})\n"
+        "import bfsm\n"
+        "c = bfsm.reference_constants()\n"
+        f"f_h = np.load({str(tmp_path / 'f.npy')!r})\n"
+        f"op = bfsm.HIPBoltzmannOperator(bfsm.GaussLegendreQuadrature({n_gl}, 0.0, c['R']), bfsm.SphericalDesign({n_sph}), {nv}, {nv}, {nv}, c['gamma'], c['b_gamma'], c['L'])\n"
+        "op.setPrecision(32); op.setMaxChunk(5); op.initialize()\n"
+        "f = torch.from_numpy(f_h).cuda(); Q = torch.empty_like(f)\n"
+        "op(Q, f); torch.cuda.synchronize()\n"
+        f"np.save({str(tmp_path / 'q.npy')!r}, Q.cpu().numpy())\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, BFSM_LIB=lib))
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = np.load(tmp_path / "q.npy")
+    assert np.abs(got - ref).max() <= TOL32 * np.abs(ref).max()
+
+
 def test_cpp_multi_gpu_driver_on_one_device(torch_cuda):
     """host/maxwell_bkw_hip_multi.cpp = the reference driver with BoltzmannOperator<HIP_MultiGPU_Backend> (single
     process, f broadcast, direction shards, ONE grouped ncclReduce on Q).  On a one-GPU box: --gpus 1 without

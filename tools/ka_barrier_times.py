@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Cycles the waves of KA's pipelined-pair loop spend inside each of its 12 barriers per direction.
 
-Needs the instrumented build:  bash tools/build_variants.sh bartimes:"-DBFSM_KA_BARRIER_TIMES"
+Needs the instrumented build:  bash tools/build_variants.sh bartimes:"-DBFSM_TOOLS_BUILD -DBFSM_KA_BARRIER_TIMES"  (+ -DBFSM_KA_XLANE: the cross-lane form, 8 barriers)
 usage: BFSM_LIB=gpurun_variants/libbfsm_bartimes.so python3 tools/ka_barrier_times.py c5s [cfg3]
 Barrier k of an iteration (csrc/bfsm_core.hpp, body_gain_inv, pipelined pair):
   0 before wr A (previous direction's last reads)   1 wr A done -> rd A     2 rd A done -> wr B
