@@ -53,6 +53,11 @@ struct GenFftParams {
     const T* beta2;
     size_t in_bstride;       // elements between batch members of in / in2 (0: shared)
     size_t out_bstride;      // elements between batch members of out
+    // plane kernel (body_gen_plane): the y and the z pass of one x-plane in one workgroup; tw / radix above describe the
+    // FIRST axis transformed (z in the forward direction, y in the backward one), these the second
+    const cx<T>* tw_b;
+    int n_radix_b;
+    int radix_b[8];
 };
 
 template <typename T>
@@ -207,6 +212,14 @@ BFSM_HD void body_gen_fft(const GenFftParams<T>& prm, Ctx& ctx) {
     else if (axis == 1) { i0x = col / nz; i0z = col - i0x * nz; base = (size_t)i0x * ny * nz + i0z; ps = (size_t)nz; }
     else { i0x = col / ny; i0y = col - i0x * ny; base = (size_t)col * nz; ps = 1; }
     const size_t in_off = (size_t)b * prm.in_bstride;
+    // GEN_PHASE: the factors of the two axes that are NOT transformed are constant along the line: one product per thread,
+    // then one table value and two complex multiplications per point instead of three and three
+    cx<T> ph_line = {(T)1, (T)0};
+    if (prm.mode == GEN_PHASE && live) {
+        const size_t d = (size_t)(prm.dir0 + (b >> 1));
+        const cx<T> px = prm.phx[d * nx + i0x], py = prm.phy[d * ny + i0y], pz = prm.phz[d * nz + i0z];
+        ph_line = axis == 0 ? cmul(py, pz) : (axis == 1 ? cmul(px, pz) : cmul(px, py));
+    }
     // the global loads are issued four points at a time before any of them is consumed: the trip count is a run-time
     // value, and a rolled loop would pay one full memory latency per point
     constexpr int STEP = GEN_THREADS / GEN_C, CH = 4;
@@ -236,7 +249,8 @@ BFSM_HD void body_gen_fft(const GenFftParams<T>& prm, Ctx& ctx) {
                         const int ix = axis == 0 ? pt : i0x, iy = axis == 1 ? pt : i0y, iz = axis == 2 ? pt : i0z;
                         if (prm.mode == GEN_PHASE) {
                             const size_t d = (size_t)(prm.dir0 + (b >> 1));
-                            const cx<T> ph = cmul(cmul(prm.phx[d * nx + ix], prm.phy[d * ny + iy]), prm.phz[d * nz + iz]);
+                            const cx<T> pa = axis == 0 ? prm.phx[d * nx + ix] : (axis == 1 ? prm.phy[d * ny + iy] : prm.phz[d * nz + iz]);
+                            const cx<T> ph = cmul(pa, ph_line);
                             v = (b & 1) ? cmulc(v, ph) : cmul(v, ph);
                         } else {
                             const int mx = gen_mode(ix, nx), my = gen_mode(iy, ny), mz = gen_mode(iz, nz);
@@ -277,6 +291,113 @@ BFSM_HD void body_gen_fft(const GenFftParams<T>& prm, Ctx& ctx) {
     }
 }
 
+// One Stockham pass of radix R over ALL nl lines of n points of a plane held in LDS; element (point pt, line l) at
+// pt * ps + l * ls.  16 lanes take 16 consecutive lines, 16 rows of threads walk the butterflies.
+template <int R, bool NS_POW2, typename T, class Ctx>
+BFSM_HD void gen_plane_pass(const cx<T>* src, cx<T>* dst, const cx<T>* tw, int n, int ns, int sgn, int nl, int ps, int ls, Ctx& ctx) {
+    const int m = n / R;
+    const int lc = ctx.tid() % GEN_C, row = ctx.tid() / GEN_C;
+    const int tstep = n / (ns * R);
+    const int sh = NS_POW2 ? (31 - __builtin_clz((unsigned)ns)) : 0;
+    for (int l0 = 0; l0 < nl; l0 += GEN_C) {
+        const int l = l0 + lc;
+        if (l >= nl) continue;
+        const cx<T>* s0 = src + (size_t)l * ls;
+        cx<T>* d0 = dst + (size_t)l * ls;
+        for (int j = row; j < m; j += GEN_THREADS / GEN_C) {
+            const int hi = NS_POW2 ? (j >> sh) : (j / ns);
+            const int k = NS_POW2 ? (j & (ns - 1)) : (j - hi * ns);
+            cx<T> x[R];
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                x[q] = s0[(j + q * m) * ps];
+                if (q > 0) {
+                    const cx<T> w = tw[k * q * tstep];
+                    x[q] = sgn < 0 ? cmul(x[q], w) : cmulc(x[q], w);
+                }
+            }
+            gen_dft<R, T>(x, sgn);
+            const int j0 = hi * ns * R + k;
+#pragma unroll
+            for (int q = 0; q < R; ++q) d0[(j0 + q * ns) * ps] = x[q];
+        }
+    }
+}
+
+template <typename T, class Ctx>
+BFSM_HD void gen_plane_axis(cx<T>*& src, cx<T>*& dst, const cx<T>* tw, const int* radix, int n_radix, int n, int sgn, int nl, int ps,
+                            int ls, Ctx& ctx) {
+    int ns = 1;
+    for (int r = 0; r < n_radix; ++r) {
+        const int R = radix[r];
+        const bool p2 = (ns & (ns - 1)) == 0;
+        if (R == 4) gen_plane_pass<4, true, T>(src, dst, tw, n, ns, sgn, nl, ps, ls, ctx);
+        else if (R == 2) gen_plane_pass<2, true, T>(src, dst, tw, n, ns, sgn, nl, ps, ls, ctx);
+        else if (R == 3 && p2) gen_plane_pass<3, true, T>(src, dst, tw, n, ns, sgn, nl, ps, ls, ctx);
+        else if (R == 3) gen_plane_pass<3, false, T>(src, dst, tw, n, ns, sgn, nl, ps, ls, ctx);
+        else if (R == 5 && p2) gen_plane_pass<5, true, T>(src, dst, tw, n, ns, sgn, nl, ps, ls, ctx);
+        else gen_plane_pass<5, false, T>(src, dst, tw, n, ns, sgn, nl, ps, ls, ctx);
+        ns *= R;
+        ctx.sync();
+        cx<T>* t = src; src = dst; dst = t;
+    }
+}
+
+// The y and the z pass of ONE x-plane fused through LDS (round 4; boxes whose plane fits: 2 ny (nz + 1) elements of LDS,
+// radices 2, 3, 5): the plane [y][z] is contiguous in memory, so the loads and stores are fully coalesced, and a 3-D
+// transform is 2 array passes here + 1 x-pass instead of 3 passes -- 12 array moves per direction instead of 18.
+// grid = (nx planes, batch).  Forward (sign -1): z then y; backward: y then z.  Same load-side fusions as body_gen_fft.
+template <typename T, class Ctx>
+BFSM_HD void body_gen_plane(const GenFftParams<T>& prm, Ctx& ctx) {
+    const int nx = prm.nx, ny = prm.ny, nz = prm.nz;
+    const int ix = ctx.bx(), b = ctx.by();
+    const int LSZ = nz + 1;                                  // LDS row stride of the plane (odd: conflict-free both ways)
+    cx<T>* buf0 = ctx.template lds<cx<T>>();
+    cx<T>* buf1 = buf0 + (size_t)ny * LSZ;
+    const size_t plane = (size_t)ny * nz, base = (size_t)ix * plane;
+    const size_t in_off = (size_t)b * prm.in_bstride;
+    // (iy, iz) of the element this thread touches, advanced by GEN_THREADS elements per step without a division
+    const int dy = GEN_THREADS / nz, dz = GEN_THREADS - dy * nz;
+    int iy = ctx.tid() / nz, iz = ctx.tid() - iy * nz;
+    for (size_t e = (size_t)ctx.tid(); e < plane; e += GEN_THREADS) {
+        const size_t idx = base + e;
+        cx<T> v = {(T)0, (T)0};
+        if (prm.mode == GEN_REAL) v.x = (T) static_cast<const double*>(prm.in)[in_off + idx];
+        else v = static_cast<const cx<T>*>(prm.in)[in_off + idx];
+        if (prm.mode == GEN_PRODUCT) v = cmul(v, prm.in2[in_off + idx]);
+        else if (prm.mode == GEN_PHASE) {
+            const size_t d = (size_t)(prm.dir0 + (b >> 1));
+            const cx<T> ph = cmul(cmul(prm.phx[d * nx + ix], prm.phy[d * ny + iy]), prm.phz[d * nz + iz]);
+            v = (b & 1) ? cmulc(v, ph) : cmul(v, ph);
+        } else if (prm.mode == GEN_BETA2) {
+            const int mx = gen_mode(ix, nx), my = gen_mode(iy, ny), mz = gen_mode(iz, nz);
+            const T b2 = prm.beta2[mx * mx + my * my + mz * mz];
+            v = {b2 * v.x, b2 * v.y};
+        }
+        buf0[iy * LSZ + iz] = v;
+        iy += dy; iz += dz;
+        if (iz >= nz) { iz -= nz; ++iy; }
+    }
+    ctx.sync();
+    cx<T>* src = buf0;
+    cx<T>* dst = buf1;
+    // first axis: z when transforming forward (lines = y rows, points contiguous), y when transforming backward
+    if (prm.sign < 0) {
+        gen_plane_axis<T>(src, dst, prm.tw, prm.radix, prm.n_radix, nz, prm.sign, ny, 1, LSZ, ctx);
+        gen_plane_axis<T>(src, dst, prm.tw_b, prm.radix_b, prm.n_radix_b, ny, prm.sign, nz, LSZ, 1, ctx);
+    } else {
+        gen_plane_axis<T>(src, dst, prm.tw, prm.radix, prm.n_radix, ny, prm.sign, nz, LSZ, 1, ctx);
+        gen_plane_axis<T>(src, dst, prm.tw_b, prm.radix_b, prm.n_radix_b, nz, prm.sign, ny, 1, LSZ, ctx);
+    }
+    const size_t out_off = (size_t)b * prm.out_bstride;
+    iy = ctx.tid() / nz; iz = ctx.tid() - iy * nz;
+    for (size_t e = (size_t)ctx.tid(); e < plane; e += GEN_THREADS) {
+        prm.out[out_off + base + e] = src[iy * LSZ + iz];
+        iy += dy; iz += dz;
+        if (iz >= nz) { iz -= nz; ++iy; }
+    }
+}
+
 template <typename T, class Ctx>
 BFSM_HD void body_gen_acc(const GenAccParams<T>& prm, Ctx& ctx) {
     const size_t G = (size_t)prm.nx * prm.ny * prm.nz;
@@ -305,7 +426,7 @@ BFSM_HD void body_gen_combine(const GenCombineParams<T>& prm, Ctx& ctx) {
     prm.Q[idx] = q;
 }
 
-enum class GK { Fft, Acc, Combine, FftBig };   // FftBig: Fft + the radix-7 / 11 / 13 passes
+enum class GK { Fft, Acc, Combine, FftBig, Plane };   // FftBig: Fft + the radix-7 / 11 / 13 passes; Plane: y and z pass fused
 
 inline bool gen_factor(int n, std::vector<int>& radix) {
     radix.clear();
@@ -371,7 +492,8 @@ struct GenericPipeline {
             return BFSM_ERR_UNSUPPORTED;
         }
         const long long B = (long long)d.n_gl * d.n_sph;
-        plan = PlanInfo();                // exact_reductions / hermitian / antipodal stay false: this path evaluates every
+        plan = PlanInfo();
+        plan.gen_plane = plane_ok();                // exact_reductions / hermitian / antipodal stay false: this path evaluates every
         plan.N = 0;                       // direction whatever the flags say (include/bfsm.h documents them as no-ops here)
         plan.Gtot = G;
         plan.precision = d.precision;
@@ -491,13 +613,45 @@ struct GenericPipeline {
         else be->template launch_gen<GK::Fft, T>((ncols + C - 1) / C, batch, GEN_THREADS, lds, p);
     }
 
+    // the fused (y,z) plane kernel serves boxes whose plane fits the LDS twice and whose y / z factors are 2, 3, 5
+    bool plane_ok() const {
+#ifdef BFSM_GEN_NO_PLANE          // A/B builds (tools only): one pass per axis everywhere
+        return false;
+#else
+        for (int ax = 1; ax <= 2; ++ax) for (int r : radix[ax]) if (r > 5) return false;
+        // ... and leaves room for four workgroups per CU: with bigger planes the one-pass-per-axis kernels (52 KB at most) win
+        // (64 x 48 x 80 in double precision, a 124 KB plane: 0.92 against 1.30 TB/s algorithmic, profiles/r04_generic_ktimes.txt)
+        return (size_t)2 * ny * (nz + 1) * sizeof(cx<T>) <= (size_t)40 * 1024 && nz <= GEN_THREADS;
+#endif
+    }
+    void plane(const void* in, const cx<T>* in2, cx<T>* out, int batch, int sign, int mode, size_t in_bstride, size_t out_bstride,
+               long long dir0 = 0) {
+        GenFftParams<T> p{};
+        p.in = in; p.in2 = in2; p.out = out;
+        p.nx = nx; p.ny = ny; p.nz = nz; p.axis = 1; p.sign = sign; p.C = GEN_C;
+        const int a = sign < 0 ? 2 : 1, bsec = sign < 0 ? 1 : 2;          // first / second axis transformed
+        p.tw = tw[a]; p.tw_b = tw[bsec];
+        p.n_radix = (int)radix[a].size();
+        for (int i = 0; i < p.n_radix; ++i) p.radix[i] = radix[a][i];
+        p.n_radix_b = (int)radix[bsec].size();
+        for (int i = 0; i < p.n_radix_b; ++i) p.radix_b[i] = radix[bsec][i];
+        p.mode = mode; p.phx = phx; p.phy = phy; p.phz = phz; p.dir0 = dir0; p.beta2 = beta2;
+        p.in_bstride = in_bstride; p.out_bstride = out_bstride;
+        const size_t lds = (size_t)2 * ny * (nz + 1) * sizeof(cx<T>);
+        be->template launch_gen<GK::Plane, T>(nx, batch, GEN_THREADS, lds, p);
+    }
+
     // f_hat = FFT(f), then the gain term of this shard into qhat   (CUDABoltzmannOperator.cu:131-191)
     void gain_partial(const double* f_dev, int nb = 1, bool = true) {
         (void)nb;
         const double Gc = (double)G * sizeof(cx<T>);
+        const bool pl = plane_ok();
         be->mark(BFSM_K_FFT_F, 1.5 * Gc);
-        pass(f_dev, nullptr, fhat, 1, 2, -1, GEN_REAL, 0, 0);
-        be->mark(BFSM_K_FFT_F, 2.0 * Gc); pass(fhat, nullptr, fhat, 1, 1, -1, GEN_PLAIN, 0, 0);
+        if (pl) plane(f_dev, nullptr, fhat, 1, -1, GEN_REAL, 0, 0);
+        else {
+            pass(f_dev, nullptr, fhat, 1, 2, -1, GEN_REAL, 0, 0);
+            be->mark(BFSM_K_FFT_F, 2.0 * Gc); pass(fhat, nullptr, fhat, 1, 1, -1, GEN_PLAIN, 0, 0);
+        }
         be->mark(BFSM_K_FFT_F, 2.0 * Gc); pass(fhat, nullptr, fhat, 1, 0, -1, GEN_PLAIN, 0, 0);
         bool first = true;
         for (const Chunk& c : plan.chunks) {
@@ -507,13 +661,19 @@ struct GenericPipeline {
             // transforms), 3 to the next (product + forward transform) and 1 to the accumulate; the path moves more
             be->mark(BFSM_K_GAIN_INV, 2.0 * c.n * Gc);
             pass(fhat, nullptr, a, nb2, 0, +1, GEN_PHASE, 0, G, c.dir0);
-            be->mark(BFSM_K_GAIN_INV, 0); pass(a, nullptr, a, nb2, 1, +1, GEN_PLAIN, G, G);
-            be->mark(BFSM_K_GAIN_INV, 0); pass(a, nullptr, a, nb2, 2, +1, GEN_PLAIN, G, G);
+            if (pl) { be->mark(BFSM_K_GAIN_INV, 0); plane(a, nullptr, a, nb2, +1, GEN_PLAIN, G, G); }
+            else {
+                be->mark(BFSM_K_GAIN_INV, 0); pass(a, nullptr, a, nb2, 1, +1, GEN_PLAIN, G, G);
+                be->mark(BFSM_K_GAIN_INV, 0); pass(a, nullptr, a, nb2, 2, +1, GEN_PLAIN, G, G);
+            }
             // P_hat = FFT(A1 * A2): the product is formed on the load side of the first forward pass and written over
             // A1 (members 2d, stride 2G), then transformed in place
             be->mark(BFSM_K_GAIN_LINE, 3.0 * c.n * Gc);
-            pass(a, a + G, a, c.n, 2, -1, GEN_PRODUCT, 2 * G, 2 * G);
-            be->mark(BFSM_K_GAIN_LINE, 0); pass(a, nullptr, a, c.n, 1, -1, GEN_PLAIN, 2 * G, 2 * G);
+            if (pl) plane(a, a + G, a, c.n, -1, GEN_PRODUCT, 2 * G, 2 * G);
+            else {
+                pass(a, a + G, a, c.n, 2, -1, GEN_PRODUCT, 2 * G, 2 * G);
+                be->mark(BFSM_K_GAIN_LINE, 0); pass(a, nullptr, a, c.n, 1, -1, GEN_PLAIN, 2 * G, 2 * G);
+            }
             be->mark(BFSM_K_GAIN_LINE, 0); pass(a, nullptr, a, c.n, 0, -1, GEN_PLAIN, 2 * G, 2 * G);
             GenAccParams<T> ka{a, 2 * G, qhat, dirw, rdir, beta1, c.dir0, c.n, n2stride, first ? 1 : 0, nx, ny, nz};
             be->mark(BFSM_K_GAIN_FWD, 1.0 * c.n * Gc);
@@ -534,13 +694,19 @@ struct GenericPipeline {
         cx<T>* tg = tail;
         cx<T>* tl = tail + G;
         be->mark(BFSM_K_TAIL, (with_loss ? 7.0 : 3.5) * Gc);
+        const bool pl = plane_ok();
+        auto yz = [&](cx<T>* t) {
+            if (pl) { be->mark(BFSM_K_TAIL, 0); plane(t, nullptr, t, 1, +1, GEN_PLAIN, 0, 0); }
+            else {
+                be->mark(BFSM_K_TAIL, 0); pass(t, nullptr, t, 1, 1, +1, GEN_PLAIN, 0, 0);
+                be->mark(BFSM_K_TAIL, 0); pass(t, nullptr, t, 1, 2, +1, GEN_PLAIN, 0, 0);
+            }
+        };
         pass(qhat, nullptr, tg, 1, 0, +1, GEN_PLAIN, 0, 0);
-        be->mark(BFSM_K_TAIL, 0); pass(tg, nullptr, tg, 1, 1, +1, GEN_PLAIN, 0, 0);
-        be->mark(BFSM_K_TAIL, 0); pass(tg, nullptr, tg, 1, 2, +1, GEN_PLAIN, 0, 0);
+        yz(tg);
         if (with_loss) {
             be->mark(BFSM_K_TAIL, 0); pass(fhat, nullptr, tl, 1, 0, +1, GEN_BETA2, 0, 0);
-            be->mark(BFSM_K_TAIL, 0); pass(tl, nullptr, tl, 1, 1, +1, GEN_PLAIN, 0, 0);
-            be->mark(BFSM_K_TAIL, 0); pass(tl, nullptr, tl, 1, 2, +1, GEN_PLAIN, 0, 0);
+            yz(tl);
         }
         GenCombineParams<T> kc{tg, tl, f_dev, Q_dev, G, with_loss ? 1 : 0};
         be->mark(BFSM_K_TAIL, 0);
@@ -549,6 +715,13 @@ struct GenericPipeline {
 
     // In-place batched 3-D transform on user data (bfsm_fft3d); natural layouts on both sides
     int fft3d(cx<T>* data, int batch, int sign) {
+        if (plane_ok()) {
+            if (sign < 0) { be->mark(-1, 0); plane(data, nullptr, data, batch, -1, GEN_PLAIN, G, G); }
+            be->mark(-1, 0);
+            pass(data, nullptr, data, batch, 0, sign, GEN_PLAIN, G, G);
+            if (sign > 0) { be->mark(-1, 0); plane(data, nullptr, data, batch, +1, GEN_PLAIN, G, G); }
+            return BFSM_OK;
+        }
         const int order[3] = {2, 1, 0};
         for (int i = 0; i < 3; ++i) {
             be->mark(-1, 0);

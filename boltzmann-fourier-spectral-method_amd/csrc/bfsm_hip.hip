@@ -386,6 +386,7 @@ __global__ void __launch_bounds__(GEN_THREADS) bfsm_gen_kernel(const P prm) {
     DevCtx ctx{bfsm_smem};
     if constexpr (kind == GK::Fft) body_gen_fft<T, false>(prm, ctx);
     else if constexpr (kind == GK::FftBig) body_gen_fft<T, true>(prm, ctx);
+    else if constexpr (kind == GK::Plane) body_gen_plane<T>(prm, ctx);
     else if constexpr (kind == GK::Acc) body_gen_acc<T>(prm, ctx);
     else if constexpr (kind == GK::Combine) body_gen_combine<T>(prm, ctx);
 }

@@ -248,6 +248,7 @@ struct EmuBackend {
         const P& prm = *static_cast<const P*>(a);
         if constexpr (kind == bfsm::GK::Fft) bfsm::body_gen_fft<T, false>(prm, ctx);
     else if constexpr (kind == bfsm::GK::FftBig) bfsm::body_gen_fft<T, true>(prm, ctx);
+    else if constexpr (kind == bfsm::GK::Plane) bfsm::body_gen_plane<T>(prm, ctx);
         else if constexpr (kind == bfsm::GK::Acc) bfsm::body_gen_acc<T>(prm, ctx);
         else if constexpr (kind == bfsm::GK::Combine) bfsm::body_gen_combine<T>(prm, ctx);
     }

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel HIP-event times (ms per evaluation, algorithmic TB/s) for a list of cases; BFSM_LIB selects the build.
 
-usage: ktimes.py CASE [CASE ...]     CASE = name[:mode] | nv,n_gl,n_sph,prec[,mode]   (mode: f faithful, e exact, h hermitian)
+usage: ktimes.py CASE [CASE ...]     CASE = name[:mode] | nv,n_gl,n_sph,prec[,mode] | NXxNYxNZ,n_gl,n_sph,prec   (mode: f faithful, e exact, h hermitian)
 named: cfg1 cfg2 cfg3 cfg4 cfg5 c5s (cfg5 grid, 4 radial nodes) d128 (N=128 fp64, 2 radial nodes x 192) f64 (cfg3 in fp32)
 """
 import os
@@ -17,17 +17,25 @@ NAMED = {"cfg1": (16, 8, 32, 64), "cfg2": (32, 8, 48, 64), "cfg3": (64, 16, 48, 
 c = bfsm.reference_constants()
 for case in sys.argv[1:]:
     mode = "f"
+    shape = None
     if case.split(":")[0] in NAMED:
         nv, n_gl, n_sph, prec = NAMED[case.split(":")[0]]
         if ":" in case:
             mode = case.split(":")[1]
     else:
         parts = case.split(",")
-        nv, n_gl, n_sph, prec = (int(a) for a in parts[:4])
+        shape = tuple(int(a) for a in parts[0].split("x")) if "x" in parts[0] else None      # NXxNYxNZ: a box (size-generic path)
+        nv = shape[0] if shape else int(parts[0])
+        n_gl, n_sph, prec = (int(a) for a in parts[1:4])
         mode = parts[4] if len(parts) > 4 else "f"
-    f = torch.from_numpy(bfsm.bkw_solution(nv)[0]).cuda()
+    shape = shape if (case.split(":")[0] not in NAMED and shape) else (nv, nv, nv)
+    if shape[0] == shape[1] == shape[2]:
+        f = torch.from_numpy(bfsm.bkw_solution(nv)[0]).cuda()
+    else:
+        import numpy as np
+        f = torch.from_numpy(np.random.default_rng(1).random(shape) + 0.1).cuda()
     Q = torch.empty_like(f)
-    op = bfsm.HIPBoltzmannOperator(bfsm.GaussLegendreQuadrature(n_gl, 0, c["R"]), bfsm.SphericalDesign(n_sph), nv, nv, nv,
+    op = bfsm.HIPBoltzmannOperator(bfsm.GaussLegendreQuadrature(n_gl, 0, c["R"]), bfsm.SphericalDesign(n_sph), shape[0], shape[1], shape[2],
                                    c["gamma"], c["b_gamma"], c["L"])
     op.setPrecision(prec)
     op.setProfiling(True)
@@ -47,7 +55,7 @@ for case in sys.argv[1:]:
         accb = [cn.kernel_alg_bytes[i] for i in range(len(bfsm.KERNEL_NAMES))]
     tot = sum(acc) / reps
     cb = 16.0 if prec == 64 else 8.0
-    alg = (6.0 * n_gl * n_sph + 9) * nv ** 3 * cb
+    alg = (6.0 * n_gl * n_sph + 9) * shape[0] * shape[1] * shape[2] * cb
     s = " ".join(f"{k}={v / reps:.3f}ms/{(b / (v / reps * 1e-3) / 1e12) if v > 0 else 0:.2f}" for k, v, b in zip(bfsm.KERNEL_NAMES, acc, accb))
     print(f"{case:10s} {os.path.basename(os.environ.get('BFSM_LIB', 'default')):28s} sum={tot:.3f}ms alg={alg / tot / 1e9:.2f}TB/s of8={alg / tot / 8e9:.3f} | {s}", flush=True)
     op.destroy()
