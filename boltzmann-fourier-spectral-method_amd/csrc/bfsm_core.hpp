@@ -1295,7 +1295,9 @@ BFSM_HD void body_gain_line(const GainLineParams<T>& prm, Ctx& ctx) {
 #pragma unroll
     for (int m = 0; m < E; ++m) a[m] = cmul(a[m], b[m]);
     fft_line_np<N, NPL, -1, T, false, 0>(a, lds, p, u, twr, ctx);
-    cx<T>* P = prm.pout + (size_t)ctx.bz() * prm.p_bstride + dcol;
+    // in place unless the scratch is interleaved: the SAME base pointer as the loads then (geometries without the scalar-base
+    // form hold per-lane 64-bit addresses -- a second base doubled them: N = 80 KB 1.71 -> 2.15 ms)
+    cx<T>* P = ab_interleaved<N, T>() ? prm.pout + (size_t)ctx.bz() * prm.p_bstride + dcol : prm.a1 + ubase;
 #pragma unroll
     for (int m = 0; m < E; ++m) ctx.template st_stream_at<UNI>(P + (size_t)(u + TT * m) * N * N, pl, a[m]);
 }
@@ -1464,7 +1466,7 @@ BFSM_HD void hermitian_lines_load(cx<T>* a, cx<T>* b, const cx<T>* A1, const cx<
     // mirror rows: row m is the conjugate of the stored row q = N - (u + T m) = (T - u) + T (E - 1 - m), 1 <= q < N/2.
     // ONE address register (the row of m = E - 1, opaque to the optimiser) + non-negative immediates: left to itself the
     // compiler kept one register per row and array -- 8 of them spilled at the 128-VGPR cap of N = 64 in double precision
-    const cx<T>* const mlo = lds + ctx.opaque_v((TT - u) * LS + p);
+    const cx<T>* const mlo = lds + ((N == 32 || N == 64) ? ctx.opaque_v((TT - u) * LS + p) : (TT - u) * LS + p);
 #pragma unroll
     for (int m = MS; m < E; ++m) {
         if (m > MS || u != 0) {
@@ -1486,31 +1488,39 @@ BFSM_HD void hermitian_line_load1(cx<T>* a, const cx<T>* A1, int colrow, unsigne
 #pragma unroll
     for (int m = 0; m < MS; ++m) ctx.lds_st(lds + (u + TT * m) * LS + p, a[m]);
     ctx.sync();
-    const cx<T>* const mlo = lds + ctx.opaque_v((TT - u) * LS + p);     // see hermitian_lines_load
 #pragma unroll
     for (int m = MS; m < E; ++m)
-        if (m > MS || u != 0) a[m] = ctx.lds_ld(mlo + TT * (E - 1 - m) * LS);
+        if (m > MS || u != 0) a[m] = ctx.lds_ld(lds + (N - (u + TT * m)) * LS + p);
 }
 
 template <int N, typename T, class Ctx>
 BFSM_HD void hermitian_line_fix(cx<T>* v, const cx<T>* R, int y, int z, int u, Ctx& ctx) {
     constexpr int E = Wg<N>::E, TT = Wg<N>::T, NQ = N / 2 - 1, H = N / 2, MS = E / 2;
     const T sy = (y & 1) ? (T)-1 : (T)1, sz = (z & 1) ? (T)-1 : (T)1;
-    const unsigned zoff = ctx.lane_off((unsigned)z * (unsigned)sizeof(cx<T>));
-    unsigned yoff = 0;
-    if constexpr (Wg<N>::NPL > N && Wg<N>::LROW % 64 == 0) yoff = ctx.lane_off((unsigned)y * (unsigned)sizeof(cx<T>));
+    // Scalar-base form of the Nyquist-row loads (wave-uniform row + one lane offset: no 64-bit address per row in VGPRs)
+    // where the kernel sits at the 128-VGPR cap -- N = 32 and 64, where the per-row addresses were what it spilled.  The
+    // other geometries keep plain loads, which the compiler schedules early (measured with the scalar-base form everywhere:
+    // N = 48 KB'H 0.119 -> 0.150 ms, N = 128 fp32 2.04 -> 2.11 ms; profiles/r04_other_sizes.txt).
+    constexpr bool SB = (N == 32 || N == 64) && Wg<N>::LROW % 64 == 0;
+    unsigned zoff = 0, yoff = 0;
+    if constexpr (SB) zoff = ctx.lane_off((unsigned)z * (unsigned)sizeof(cx<T>));
+    if constexpr (SB && Wg<N>::NPL > N) yoff = ctx.lane_off((unsigned)y * (unsigned)sizeof(cx<T>));
 #pragma unroll
     for (int m = MS; m < E; ++m) {
         const bool mir = (m > MS) || u != 0;
         const int j = mir ? u + TT * m - (H + 1) : 0;
         // wave-uniform row + one lane offset (scalar-base load: no 64-bit address per row held in VGPRs across the
         // direction loop -- they were what the kernel spilled at the 128-VGPR cap)
-        const int ju = ctx.uniform(j, Wg<N>::LROW);              // (wave-uniform wherever a row of lanes is whole waves)
-        const cx<T> r1 = ctx.template ld_at<Wg<N>::LROW % 64 == 0>(R + (size_t)ju * N, zoff);
-        cx<T> r2;
-        if constexpr (Wg<N>::NPL > N && Wg<N>::LROW % 64 == 0)       // N = 32: y differs inside a wave, the row does not
-            r2 = ctx.template ld_at<true>(R + (size_t)(NQ + ju) * N, yoff);
-        else r2 = ctx.ldc(R + (size_t)(NQ + ju) * N + y);           // (j, y) are wave-uniform for N >= 64
+        cx<T> r1, r2;
+        if constexpr (SB) {
+            const int ju = ctx.uniform(j, Wg<N>::LROW);          // (wave-uniform: a row of lanes is whole waves here)
+            r1 = ctx.template ld_at<true>(R + (size_t)ju * N, zoff);
+            if constexpr (Wg<N>::NPL > N) r2 = ctx.template ld_at<true>(R + (size_t)(NQ + ju) * N, yoff);   // N = 32: y differs inside a wave
+            else r2 = ctx.ldc(R + (size_t)(NQ + ju) * N + y);   // (j, y) are wave-uniform
+        } else {
+            r1 = R[(size_t)j * N + z];
+            r2 = ctx.ldc(R + (size_t)(NQ + j) * N + y);          // (j, y) are wave-uniform for N >= 64
+        }
         const T k = mir ? (T)1 : (T)0, c = mir ? (T)-1 : (T)1;
         v[m] = {v[m].x + k * (sy * r1.x + sz * r2.x), c * v[m].y + k * (sy * r1.y + sz * r2.y)};
     }
@@ -1578,8 +1588,11 @@ BFSM_HD void body_gain_line_acc_h(const GainLineAccHParams<T>& prm, Ctx& ctx) {
     const size_t obase = (size_t)ctx.bz() * prm.pseg_bstride + (size_t)(prm.seg0 + gby) * N * N * N + colrow;
     // the lane offset of the final stores is re-derived from the thread id (not kept in a register across the direction
     // loop: at the 128-VGPR cap of N = 64 in double precision that one value went to scratch)
-    const int pr3 = ctx.opaque_v(ctx.tid()) % Wg<N>::LROW;
-    const unsigned pl3 = (unsigned)((Wg<N>::LROW == NPL || pr3 < NPL) ? pr3 : pr3 - (Wg<N>::LROW - NPL)) * (unsigned)sizeof(cx<T>);
+    unsigned pl3 = pl;
+    if constexpr (N == 32 || N == 64) {
+        const int pr3 = ctx.opaque_v(ctx.tid()) % Wg<N>::LROW;
+        pl3 = (unsigned)((Wg<N>::LROW == NPL || pr3 < NPL) ? pr3 : pr3 - (Wg<N>::LROW - NPL)) * (unsigned)sizeof(cx<T>);
+    }
 #pragma unroll
     for (int m = 0; m < E; ++m)
         ctx.template st_at<Wg<N>::LROW % 64 == 0>(prm.pseg + obase + (size_t)(u + TT * m) * N * N, pl3, acc[m]);
