@@ -390,6 +390,28 @@ def test_n128_fp32_matches_oracle(torch_cuda, oracle):
         got = _collide(torch_cuda, op, f_h)
         op.destroy()
         assert np.abs(got - ref).max() <= TOL32 * np.abs(ref).max()
+    # the interleaved {A1', A2'} scratch of this geometry (faithful and exact modes; two arrays in the Hermitian mode) with
+    # chunks, a batch of two (batch strides of the pairs and of P') and a pair of direction shards
+    torch = torch_cuda
+    fb = torch.from_numpy(np.stack([f_h, 0.5 * f_h])).cuda()
+    for exact, herm in ((False, False), (True, False), (True, True)):
+        op = _make(bfsm, nv, n_gl, n_sph, 32, exact=exact, hermitian=herm, max_chunk=7, max_batch=2)
+        Qb = torch.empty_like(fb)
+        op.computeCollisionBatch(Qb, fb, 2)
+        torch.cuda.synchronize()
+        op.destroy()
+        assert np.abs(Qb[0].cpu().numpy() - ref).max() <= TOL32 * np.abs(ref).max(), (exact, herm)
+        assert np.abs(Qb[1].cpu().numpy() - 0.25 * ref).max() <= TOL32 * np.abs(ref).max(), (exact, herm)
+    f = torch.from_numpy(f_h).cuda()
+    total = 0
+    for r in range(2):
+        op = _make(bfsm, nv, n_gl, n_sph, 32, shard=bfsm.shard_range(n_gl * n_sph, r, 2), max_chunk=5)
+        Q = torch.empty_like(f)
+        op.collidePartial(Q, f, r == 0)
+        torch.cuda.synchronize()
+        total = total + Q.cpu().numpy()
+        op.destroy()
+    assert np.abs(total - ref).max() <= TOL32 * np.abs(ref).max()
 
 
 def test_n128_fp64_matches_oracle(torch_cuda, oracle):
