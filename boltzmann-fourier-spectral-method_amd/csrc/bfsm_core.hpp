@@ -773,9 +773,6 @@ template <int N, typename T> constexpr bool ab_interleaved() {
 #endif
 }
 
-#ifndef BFSM_DRAIN64            // A/B builds (tools only): 1 = drain the pre-header loads of KA's pair loop at N = 64 fp64 as well
-#define BFSM_DRAIN64 0
-#endif
 // A/B build (tools: -DBFSM_KA_XLANE): the LAST line pass of each KA tile at N = 128 fp32 as a wave-private pass.  The
 // transposing read hands every wave 8 columns with the 8 threads of a line at lane bits 3..5, the exchange between the two
 // register steps is done across lanes (v_permlane32_swap, v_permlane16_swap, DPP row_ror:8: DevCtx::xlane_transpose8) instead
@@ -1019,7 +1016,12 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
         // no per-iteration vmcnt(0) (= store drain) at the loop header, see DevCtx::drain_loads.  Not at N = 64 in double
         // precision: the write-bound geometry with two workgroups per CU shows no difference either way inside the spread of
         // its two box states (profiles/r04_ka_drain64_ab.txt), so the headline configurations keep their round-3 code
-        if constexpr (!(N == 64 && sizeof(T) == 8) || BFSM_DRAIN64) ctx.drain_loads();
+#ifdef BFSM_DRAIN64             // A/B builds (tools only): drain the pre-header loads at N = 64 fp64 as well
+        constexpr bool DRAIN = true;
+#else
+        constexpr bool DRAIN = !(N == 64 && sizeof(T) == 8);
+#endif
+        if constexpr (DRAIN) ctx.drain_loads();
         for (int d = d_begin; d < d_end; ++d) {
             const size_t b = (size_t)(prm.dir0 + d);
             const cx<T> c0 = cmul(ctx.ldc(prm.phx + b * N + lxi), py);
@@ -2014,3 +2016,5 @@ BFSM_HD void body_small_reduce(const SmallReduceParams<T>& prm, Ctx& ctx) {
 }
 
 }  // namespace bfsm
+
+#undef BFSM_SYNC_FIX

@@ -71,7 +71,6 @@ struct EmuCtx {
     unsigned lane_off(unsigned v) const { return v; }
     template <class U> U opaque_cx(U v) const { return v; }
     template <class T> void keep_alive(T) const {}
-    template <class U> U* uniform_ptr(U* p) const { return p; }
     void wave_sync();  // ordering point inside one wave of 64 threads
 };
 
