@@ -84,3 +84,19 @@ def test_measured_tables_are_generated_from_profiles():
         out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "design_tables.py"), tag, "--check"],
                              capture_output=True, text=True, timeout=120)
         assert out.returncode == 0, out.stderr
+
+
+def test_knockout_macros_need_the_tools_build_switch():
+    """The knock-out / instrumentation macros compute wrong results on purpose (tools only).  A stray -DBFSM_KO_* in an embedding
+    build must not silently yield a library without barriers or stores: without -DBFSM_TOOLS_BUILD the source refuses to
+    compile (preprocess-only run: fast), with it the library names itself a tools build in bfsm_backend_name()."""
+    import subprocess
+    src = os.path.join(ROOT, "boltzmann-fourier-spectral-method_amd", "csrc", "bfsm_hip.hip")
+    base = ["/opt/rocm/bin/hipcc", "-E", "-std=c++17", "--offload-arch=gfx950", src, "-o", os.devnull]
+    for macro in ("BFSM_KO_SYNC", "BFSM_KO_LDS", "BFSM_KO_STORE", "BFSM_KO_DFT", "BFSM_KA_BARRIER_TIMES"):
+        bad = subprocess.run(base + ["-D" + macro], capture_output=True, text=True, timeout=300)
+        assert bad.returncode != 0 and "tools-only builds" in bad.stderr, macro
+        ok = subprocess.run(base + ["-D" + macro, "-DBFSM_TOOLS_BUILD"], capture_output=True, text=True, timeout=300)
+        assert ok.returncode == 0, ok.stderr[-500:]
+    text = open(src).read()
+    assert 'return "HIP (tools build' in text and '#ifdef BFSM_TOOLS_BUILD' in text
