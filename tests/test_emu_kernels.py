@@ -81,7 +81,9 @@ def test_collide_n128_fp32_pipelined_pair_matches_oracle(oracle):
     f = oracle.perturbed_input(f)
     gl = oracle.gauss_legendre(1, 0.0, R)
     sph = oracle.spherical_design(6)
-    Q, qhat = E.collide(f, gl, sph, GAMMA, B_GAMMA, L, 32)
+    # two chunks of three directions: the interleaved {A1', A2'} scratch and the P' buffer of this geometry are re-used by
+    # the second chunk with its own direction offset (round 4)
+    Q, qhat = E.collide(f, gl, sph, GAMMA, B_GAMMA, L, 32, max_chunk=4)
     Qo, qo = oracle.collide(f, gl, sph, GAMMA, B_GAMMA, L, return_qhat=True)
     assert np.abs(qhat - qo).max() <= 2e-5 * np.abs(qo).max()           # fp32 rounding: measured 7.6e-6
 
