@@ -1981,6 +1981,12 @@ BFSM_HD void body_small_gain(const SmallGainParams<T>& prm, Ctx& ctx) {
         // the owner of the loss term transforms beta2 * f_hat / G alongside (compute_beta2_times_f_hat, Kernels.cu:126-159;
         // inverse transforms cu:203-212) and combines: share - Re(loss) * f   (compute_Q_total, Kernels.cu:162-177)
         cx<T> v[2][16];
+        // f again, fetched BEFORE the transforms so that its latency hides behind them: this workgroup's tail sets the kernel's
+        // duration when every CU is busy (256 directions on 256 CUs: 27.0 -> 22.1 us; prefetching the phase and beta1 factors
+        // the same way gained nothing and cost six registers -- profiles/r04_cfg1_prefetch_ab.txt)
+        double fre[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) fre[k] = prm.f[(i * 16 + j) * 16 + k];
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const int mx = mode_of(k, 16);
@@ -1991,7 +1997,7 @@ BFSM_HD void body_small_gain(const SmallGainParams<T>& prm, Ctx& ctx) {
         small_fft_inv<2, T>(v, lds, i, j, ctx);
 #pragma unroll
         for (int k = 0; k < 16; ++k)
-            dst[(i * 16 + j) * 16 + k] = (T)((double)v[0][k].x - (double)v[1][k].x * prm.f[(i * 16 + j) * 16 + k]);
+            dst[(i * 16 + j) * 16 + k] = (T)((double)v[0][k].x - (double)v[1][k].x * fre[k]);
     }
 }
 
