@@ -75,6 +75,36 @@ struct GenAccParams {        // Q_hat[l] (+)= sum_d dirw[d] beta1[r(d)][|l|^2] P
     int nx, ny, nz;
 };
 
+// Fused sequence of the boxes whose (y,z) plane fits the LDS (round 4): the three kernels of the cubic pipeline in
+// size-generic form -- 6 array moves per direction instead of 12.
+template <typename T>
+struct GenLineParams {       // x part of both inverse transforms + product + x part of the forward transform
+    cx<T>* a;                // [2 n][G]: A1', A2' of direction d at members 2d, 2d + 1 ([lx][y][z]); P' overwrites member 2d
+    const cx<T>* tw;         // x-axis twiddles
+    int nx, ny, nz;
+    int n_radix;
+    int radix[8];
+};
+
+template <typename T>
+struct GenPlaneAccParams {   // (y,z) part of the forward transform + weighted sum over a group of directions
+    const cx<T>* p;          // P' of direction d at p + d * p_bstride
+    size_t p_bstride;
+    cx<T>* slab;             // [groups][G]: sum over the group's directions of dirw beta1 P_hat
+    const T* dirw;
+    const int* rdir;
+    const T* beta1;
+    long long dir0;          // shard index of the chunk's first direction
+    int n;                   // directions of the chunk
+    int per_group;
+    int n2stride;
+    int nx, ny, nz;
+    const cx<T>* tw;         // z axis (transformed first), then y
+    const cx<T>* tw_b;
+    int n_radix, n_radix_b;
+    int radix[8], radix_b[8];
+};
+
 template <typename T>
 struct GenCombineParams {    // Q = Re(gain) - Re(loss) * f   (compute_Q_total, Kernels.cu:162-177)
     const cx<T>* g;
@@ -102,6 +132,19 @@ BFSM_HD void gen_dft(cx<T>* x, int sgn) {
         x[2] = csub(a, c);
         x[1] = cadd(b, id);
         x[3] = csub(b, id);
+    } else if constexpr (R == 8) {
+        // two radix-4 transforms of the even / odd inputs, then X[k], X[k + 4] = E[k] +- w^k O[k], w = exp(sgn 2 pi i / 8)
+        cx<T> e[4] = {x[0], x[2], x[4], x[6]}, o[4] = {x[1], x[3], x[5], x[7]};
+        gen_dft<4, T>(e, sgn);
+        gen_dft<4, T>(o, sgn);
+        const T h = (T)0.70710678118654752440;
+        const cx<T> o1 = sgn > 0 ? cx<T>{h * (o[1].x - o[1].y), h * (o[1].x + o[1].y)} : cx<T>{h * (o[1].x + o[1].y), h * (o[1].y - o[1].x)};
+        const cx<T> o2 = sgn > 0 ? cx<T>{-o[2].y, o[2].x} : cx<T>{o[2].y, -o[2].x};
+        const cx<T> o3 = sgn > 0 ? cx<T>{-h * (o[3].x + o[3].y), h * (o[3].x - o[3].y)} : cx<T>{h * (o[3].y - o[3].x), -h * (o[3].x + o[3].y)};
+        x[0] = cadd(e[0], o[0]); x[4] = csub(e[0], o[0]);
+        x[1] = cadd(e[1], o1);   x[5] = csub(e[1], o1);
+        x[2] = cadd(e[2], o2);   x[6] = csub(e[2], o2);
+        x[3] = cadd(e[3], o3);   x[7] = csub(e[3], o3);
     } else if constexpr (R == 3) {
         const T c = (T)-0.5, s = (T)(sgn * 0.86602540378443864676);
         const cx<T> t1 = cadd(x[1], x[2]), t2 = csub(x[1], x[2]);
@@ -156,6 +199,14 @@ constexpr int GEN_LS = GEN_C + 1;
 // One Stockham pass of radix R over GEN_C lines of n points held in LDS as [point][line] (row stride GEN_LS).
 // ns = product of the radices already applied; NS_POW2: ns is a power of two (shift / mask instead of division: the
 // plan orders the radices 4, 2 first and 3, 5 last, so only passes behind an odd radix take the general form).
+// The axis' twiddle table copied into LDS next to the line buffers: a pass reads R - 1 table values per butterfly, and a
+// global (cached) load costs a pass most of a microsecond of latency that nothing hides in workgroups this small
+// (round 4: the y/z plane kernel of 32 x 64 x 16 took 10 us per workgroup, half of it waiting for twiddles).
+template <typename T, class Ctx>
+BFSM_HD void gen_stage_tw(cx<T>* dst, const cx<T>* tw, int n, Ctx& ctx) {
+    for (int i = ctx.tid(); i < n; i += GEN_THREADS) dst[i] = tw[i];
+}
+
 template <int R, bool NS_POW2, typename T, class Ctx>
 BFSM_HD void gen_pass(const cx<T>* src, cx<T>* dst, const cx<T>* tw, int n, int ns, int sgn, Ctx& ctx) {
     const int m = n / R;
@@ -198,6 +249,8 @@ BFSM_HD void body_gen_fft(const GenFftParams<T>& prm, Ctx& ctx) {
     const int b = ctx.by();
     cx<T>* buf0 = ctx.template lds<cx<T>>();
     cx<T>* buf1 = buf0 + (size_t)n * GEN_LS;
+    cx<T>* twl = buf1 + (size_t)n * GEN_LS;
+    gen_stage_tw<T>(twl, prm.tw, n, ctx);
     // Global <-> LDS: lanes run along the contiguous (z) direction of memory.  Axes x, y: 16 consecutive lanes take
     // the 16 lines of the block at one point; axis z: 16 consecutive lanes take 16 consecutive points of one line.
     const int lane16 = ctx.tid() % GEN_C, grp = ctx.tid() / GEN_C;
@@ -270,16 +323,17 @@ BFSM_HD void body_gen_fft(const GenFftParams<T>& prm, Ctx& ctx) {
     for (int r = 0; r < prm.n_radix; ++r) {
         const int R = prm.radix[r];
         const bool p2 = (ns & (ns - 1)) == 0;
-        if (R == 4) gen_pass<4, true, T>(src, dst, prm.tw, n, ns, prm.sign, ctx);          // radices 4, 2 come first
-        else if (R == 2) gen_pass<2, true, T>(src, dst, prm.tw, n, ns, prm.sign, ctx);
-        else if (R == 3 && p2) gen_pass<3, true, T>(src, dst, prm.tw, n, ns, prm.sign, ctx);
-        else if (R == 3) gen_pass<3, false, T>(src, dst, prm.tw, n, ns, prm.sign, ctx);
-        else if (R == 5 && p2) gen_pass<5, true, T>(src, dst, prm.tw, n, ns, prm.sign, ctx);
-        else if (R == 5) gen_pass<5, false, T>(src, dst, prm.tw, n, ns, prm.sign, ctx);
+        if (R == 8) gen_pass<8, true, T>(src, dst, twl, n, ns, prm.sign, ctx);          // radices 8, 4, 2 come first
+        else if (R == 4) gen_pass<4, true, T>(src, dst, twl, n, ns, prm.sign, ctx);
+        else if (R == 2) gen_pass<2, true, T>(src, dst, twl, n, ns, prm.sign, ctx);
+        else if (R == 3 && p2) gen_pass<3, true, T>(src, dst, twl, n, ns, prm.sign, ctx);
+        else if (R == 3) gen_pass<3, false, T>(src, dst, twl, n, ns, prm.sign, ctx);
+        else if (R == 5 && p2) gen_pass<5, true, T>(src, dst, twl, n, ns, prm.sign, ctx);
+        else if (R == 5) gen_pass<5, false, T>(src, dst, twl, n, ns, prm.sign, ctx);
         else if constexpr (BIG) {
-            if (R == 7) gen_pass<7, false, T>(src, dst, prm.tw, n, ns, prm.sign, ctx);
-            else if (R == 11) gen_pass<11, false, T>(src, dst, prm.tw, n, ns, prm.sign, ctx);
-            else gen_pass<13, false, T>(src, dst, prm.tw, n, ns, prm.sign, ctx);
+            if (R == 7) gen_pass<7, false, T>(src, dst, twl, n, ns, prm.sign, ctx);
+            else if (R == 11) gen_pass<11, false, T>(src, dst, twl, n, ns, prm.sign, ctx);
+            else gen_pass<13, false, T>(src, dst, twl, n, ns, prm.sign, ctx);
         }
         ns *= R;
         ctx.sync();
@@ -292,35 +346,33 @@ BFSM_HD void body_gen_fft(const GenFftParams<T>& prm, Ctx& ctx) {
 }
 
 // One Stockham pass of radix R over ALL nl lines of n points of a plane held in LDS; element (point pt, line l) at
-// pt * ps + l * ls.  16 lanes take 16 consecutive lines, 16 rows of threads walk the butterflies.
+// pt * ps + l * ls.  The nl * n / R butterflies are dealt to the threads as one flat range, lanes along the lines (unit or
+// odd stride in LDS either way), so that every thread works whenever the plane has 256 butterflies to give.
 template <int R, bool NS_POW2, typename T, class Ctx>
 BFSM_HD void gen_plane_pass(const cx<T>* src, cx<T>* dst, const cx<T>* tw, int n, int ns, int sgn, int nl, int ps, int ls, Ctx& ctx) {
     const int m = n / R;
-    const int lc = ctx.tid() % GEN_C, row = ctx.tid() / GEN_C;
     const int tstep = n / (ns * R);
     const int sh = NS_POW2 ? (31 - __builtin_clz((unsigned)ns)) : 0;
-    for (int l0 = 0; l0 < nl; l0 += GEN_C) {
-        const int l = l0 + lc;
-        if (l >= nl) continue;
+    const int total = nl * m;
+    for (int w = ctx.tid(); w < total; w += GEN_THREADS) {
+        const int j = w / nl, l = w - j * nl;
         const cx<T>* s0 = src + (size_t)l * ls;
         cx<T>* d0 = dst + (size_t)l * ls;
-        for (int j = row; j < m; j += GEN_THREADS / GEN_C) {
-            const int hi = NS_POW2 ? (j >> sh) : (j / ns);
-            const int k = NS_POW2 ? (j & (ns - 1)) : (j - hi * ns);
-            cx<T> x[R];
+        const int hi = NS_POW2 ? (j >> sh) : (j / ns);
+        const int k = NS_POW2 ? (j & (ns - 1)) : (j - hi * ns);
+        cx<T> x[R];
 #pragma unroll
-            for (int q = 0; q < R; ++q) {
-                x[q] = s0[(j + q * m) * ps];
-                if (q > 0) {
-                    const cx<T> w = tw[k * q * tstep];
-                    x[q] = sgn < 0 ? cmul(x[q], w) : cmulc(x[q], w);
-                }
+        for (int q = 0; q < R; ++q) {
+            x[q] = s0[(j + q * m) * ps];
+            if (q > 0) {
+                const cx<T> wq = tw[k * q * tstep];
+                x[q] = sgn < 0 ? cmul(x[q], wq) : cmulc(x[q], wq);
             }
-            gen_dft<R, T>(x, sgn);
-            const int j0 = hi * ns * R + k;
-#pragma unroll
-            for (int q = 0; q < R; ++q) d0[(j0 + q * ns) * ps] = x[q];
         }
+        gen_dft<R, T>(x, sgn);
+        const int j0 = hi * ns * R + k;
+#pragma unroll
+        for (int q = 0; q < R; ++q) d0[(j0 + q * ns) * ps] = x[q];
     }
 }
 
@@ -331,7 +383,8 @@ BFSM_HD void gen_plane_axis(cx<T>*& src, cx<T>*& dst, const cx<T>* tw, const int
     for (int r = 0; r < n_radix; ++r) {
         const int R = radix[r];
         const bool p2 = (ns & (ns - 1)) == 0;
-        if (R == 4) gen_plane_pass<4, true, T>(src, dst, tw, n, ns, sgn, nl, ps, ls, ctx);
+        if (R == 8) gen_plane_pass<8, true, T>(src, dst, tw, n, ns, sgn, nl, ps, ls, ctx);
+        else if (R == 4) gen_plane_pass<4, true, T>(src, dst, tw, n, ns, sgn, nl, ps, ls, ctx);
         else if (R == 2) gen_plane_pass<2, true, T>(src, dst, tw, n, ns, sgn, nl, ps, ls, ctx);
         else if (R == 3 && p2) gen_plane_pass<3, true, T>(src, dst, tw, n, ns, sgn, nl, ps, ls, ctx);
         else if (R == 3) gen_plane_pass<3, false, T>(src, dst, tw, n, ns, sgn, nl, ps, ls, ctx);
@@ -354,6 +407,10 @@ BFSM_HD void body_gen_plane(const GenFftParams<T>& prm, Ctx& ctx) {
     const int LSZ = nz + 1;                                  // LDS row stride of the plane (odd: conflict-free both ways)
     cx<T>* buf0 = ctx.template lds<cx<T>>();
     cx<T>* buf1 = buf0 + (size_t)ny * LSZ;
+    cx<T>* twa = buf1 + (size_t)ny * LSZ;                    // twiddles of the first axis transformed, then of the second
+    cx<T>* twb = twa + (prm.sign < 0 ? nz : ny);
+    gen_stage_tw<T>(twa, prm.tw, prm.sign < 0 ? nz : ny, ctx);
+    gen_stage_tw<T>(twb, prm.tw_b, prm.sign < 0 ? ny : nz, ctx);
     const size_t plane = (size_t)ny * nz, base = (size_t)ix * plane;
     const size_t in_off = (size_t)b * prm.in_bstride;
     // (iy, iz) of the element this thread touches, advanced by GEN_THREADS elements per step without a division
@@ -383,16 +440,178 @@ BFSM_HD void body_gen_plane(const GenFftParams<T>& prm, Ctx& ctx) {
     cx<T>* dst = buf1;
     // first axis: z when transforming forward (lines = y rows, points contiguous), y when transforming backward
     if (prm.sign < 0) {
-        gen_plane_axis<T>(src, dst, prm.tw, prm.radix, prm.n_radix, nz, prm.sign, ny, 1, LSZ, ctx);
-        gen_plane_axis<T>(src, dst, prm.tw_b, prm.radix_b, prm.n_radix_b, ny, prm.sign, nz, LSZ, 1, ctx);
+        gen_plane_axis<T>(src, dst, twa, prm.radix, prm.n_radix, nz, prm.sign, ny, 1, LSZ, ctx);
+        gen_plane_axis<T>(src, dst, twb, prm.radix_b, prm.n_radix_b, ny, prm.sign, nz, LSZ, 1, ctx);
     } else {
-        gen_plane_axis<T>(src, dst, prm.tw, prm.radix, prm.n_radix, ny, prm.sign, nz, LSZ, 1, ctx);
-        gen_plane_axis<T>(src, dst, prm.tw_b, prm.radix_b, prm.n_radix_b, nz, prm.sign, ny, 1, LSZ, ctx);
+        gen_plane_axis<T>(src, dst, twa, prm.radix, prm.n_radix, ny, prm.sign, nz, LSZ, 1, ctx);
+        gen_plane_axis<T>(src, dst, twb, prm.radix_b, prm.n_radix_b, nz, prm.sign, ny, 1, LSZ, ctx);
     }
     const size_t out_off = (size_t)b * prm.out_bstride;
     iy = ctx.tid() / nz; iz = ctx.tid() - iy * nz;
     for (size_t e = (size_t)ctx.tid(); e < plane; e += GEN_THREADS) {
         prm.out[out_off + base + e] = src[iy * LSZ + iz];
+        iy += dy; iz += dz;
+        if (iz >= nz) { iz -= nz; ++iy; }
+    }
+}
+
+// All Stockham passes of one axis over the GEN_C lines of a block held in LDS (the loop of body_gen_fft, radices 2..5)
+template <typename T, class Ctx>
+BFSM_HD void gen_line_axis(cx<T>*& src, cx<T>*& dst, const cx<T>* tw, const int* radix, int n_radix, int n, int sgn, Ctx& ctx) {
+    int ns = 1;
+    for (int r = 0; r < n_radix; ++r) {
+        const int R = radix[r];
+        const bool p2 = (ns & (ns - 1)) == 0;
+        if (R == 8) gen_pass<8, true, T>(src, dst, tw, n, ns, sgn, ctx);
+        else if (R == 4) gen_pass<4, true, T>(src, dst, tw, n, ns, sgn, ctx);
+        else if (R == 2) gen_pass<2, true, T>(src, dst, tw, n, ns, sgn, ctx);
+        else if (R == 3 && p2) gen_pass<3, true, T>(src, dst, tw, n, ns, sgn, ctx);
+        else if (R == 3) gen_pass<3, false, T>(src, dst, tw, n, ns, sgn, ctx);
+        else if (R == 5 && p2) gen_pass<5, true, T>(src, dst, tw, n, ns, sgn, ctx);
+        else gen_pass<5, false, T>(src, dst, tw, n, ns, sgn, ctx);
+        ns *= R;
+        ctx.sync();
+        cx<T>* t = src; src = dst; dst = t;
+    }
+}
+
+// x-lines of one direction: A1 = IFFT_x(A1'), A2 = IFFT_x(A2'), P = A1 * A2 (hadamard_product, Kernels.cu:62-74),
+// P' = FFT_x(P), written over A1' -- what KB does on the cubes.  grid = (blocks of GEN_C lines, directions); LDS = three
+// buffers of nx x (GEN_C + 1): the second transform ping-pongs between the third buffer and the one the first left free.
+template <typename T, class Ctx>
+BFSM_HD void body_gen_line3(const GenLineParams<T>& prm, Ctx& ctx) {
+    const int n = prm.nx;
+    const size_t ps = (size_t)prm.ny * prm.nz, G = ps * (size_t)n;
+    cx<T>* X = ctx.template lds<cx<T>>();
+    cx<T>* Y = X + (size_t)n * GEN_LS;
+    cx<T>* Z = Y + (size_t)n * GEN_LS;
+    cx<T>* twl = Z + (size_t)n * GEN_LS;
+    gen_stage_tw<T>(twl, prm.tw, n, ctx);
+    const int cl = ctx.tid() % GEN_C, p0 = ctx.tid() / GEN_C;
+    const size_t col = (size_t)ctx.bx() * GEN_C + cl;
+    const bool live = col < ps;
+    cx<T>* A1 = prm.a + (size_t)ctx.by() * 2 * G + col;
+    const cx<T>* A2 = A1 + G;
+    constexpr int STEP = GEN_THREADS / GEN_C, CH = 4;
+    for (int pc = p0; pc < n; pc += CH * STEP) {
+        cx<T> v1[CH], v2[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int pt = pc + i * STEP;
+            v1[i] = {(T)0, (T)0};
+            v2[i] = {(T)0, (T)0};
+            if (live && pt < n) { v1[i] = A1[(size_t)pt * ps]; v2[i] = A2[(size_t)pt * ps]; }
+        }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int pt = pc + i * STEP;
+            if (pt < n) { X[pt * GEN_LS + cl] = v1[i]; Z[pt * GEN_LS + cl] = v2[i]; }
+        }
+    }
+    ctx.sync();
+    cx<T>* src = X;
+    cx<T>* dst = Y;
+    gen_line_axis<T>(src, dst, twl, prm.radix, prm.n_radix, n, +1, ctx);
+    cx<T>* r1 = src;                         // A1 along x; dst is free
+    src = Z;
+    gen_line_axis<T>(src, dst, twl, prm.radix, prm.n_radix, n, +1, ctx);
+    for (int pt = p0; pt < n; pt += STEP) r1[pt * GEN_LS + cl] = cmul(r1[pt * GEN_LS + cl], src[pt * GEN_LS + cl]);
+    ctx.sync();
+    dst = src;                               // A2 is consumed: its buffer is the forward transform's second one
+    src = r1;
+    gen_line_axis<T>(src, dst, twl, prm.radix, prm.n_radix, n, -1, ctx);
+    if (live)
+        for (int pt = p0; pt < n; pt += STEP) A1[(size_t)pt * ps] = src[pt * GEN_LS + cl];
+}
+
+// (y,z) forward transform + accumulate, KC of the cubes in size-generic form.  grid = (nx planes, groups of directions).
+// The workgroup streams the P' planes of its directions once, summing dirw_d P'_d in LDS while the radial node stays the
+// same (the transform is linear: one transform per run of equal radial nodes, like kc_sum_before_transform on the
+// cubes), transforms the sum, weights it with beta1[r](|l|^2) (atomic_tensor_contraction, Kernels.cu:79-123, without the
+// atomics) and adds it to a spectral accumulator; one slab plane per workgroup leaves at the end.  LDS: three planes.
+template <typename T, class Ctx>
+BFSM_HD void body_gen_plane_acc(const GenPlaneAccParams<T>& prm, Ctx& ctx) {
+    const int nx = prm.nx, ny = prm.ny, nz = prm.nz;
+    const int ix = ctx.bx(), g = ctx.by();
+    const int LSZ = nz + 1;
+    cx<T>* S = ctx.template lds<cx<T>>();
+    cx<T>* W = S + (size_t)ny * LSZ;
+    cx<T>* Qa = W + (size_t)ny * LSZ;
+    cx<T>* twa = Qa + (size_t)ny * LSZ;
+    cx<T>* twb = twa + nz;
+    gen_stage_tw<T>(twa, prm.tw, nz, ctx);
+    gen_stage_tw<T>(twb, prm.tw_b, ny, ctx);
+    const size_t plane = (size_t)ny * nz, base = (size_t)ix * plane;
+    const int dy = GEN_THREADS / nz, dz = GEN_THREADS - dy * nz;
+    const int iy0 = ctx.tid() / nz, iz0 = ctx.tid() - iy0 * nz;
+    int iy = iy0, iz = iz0;
+    for (size_t e = (size_t)ctx.tid(); e < plane; e += GEN_THREADS) {
+        S[iy * LSZ + iz] = {(T)0, (T)0};
+        Qa[iy * LSZ + iz] = {(T)0, (T)0};
+        iy += dy; iz += dz;
+        if (iz >= nz) { iz -= nz; ++iy; }
+    }
+    const int mx = gen_mode(ix, nx);
+    // transform the sum S of the finished run, weight it, add it to Qa, clear S.  Every thread touches its own elements
+    // outside the transform, whose passes end in barriers.
+    auto flush = [&](int r) {
+        ctx.sync();
+        cx<T>* src = S;
+        cx<T>* dst = W;
+        gen_plane_axis<T>(src, dst, twa, prm.radix, prm.n_radix, nz, -1, ny, 1, LSZ, ctx);
+        gen_plane_axis<T>(src, dst, twb, prm.radix_b, prm.n_radix_b, ny, -1, nz, LSZ, 1, ctx);
+        const T* b1 = prm.beta1 + (size_t)r * prm.n2stride;
+        int jy = iy0, jz = iz0;
+        for (size_t e = (size_t)ctx.tid(); e < plane; e += GEN_THREADS) {
+            const int my = gen_mode(jy, ny), mz = gen_mode(jz, nz);
+            const T b = b1[mx * mx + my * my + mz * mz];
+            const cx<T> v = src[jy * LSZ + jz];
+            cx<T> q = Qa[jy * LSZ + jz];
+            q.x += b * v.x;
+            q.y += b * v.y;
+            Qa[jy * LSZ + jz] = q;
+            S[jy * LSZ + jz] = {(T)0, (T)0};
+            jy += dy; jz += dz;
+            if (jz >= nz) { jz -= nz; ++jy; }
+        }
+        ctx.sync();                          // src may be W: the next run's transform overwrites it
+    };
+    const int d0 = g * prm.per_group;
+    int d1 = d0 + prm.per_group;
+    if (d1 > prm.n) d1 = prm.n;
+    int rcur = d0 < d1 ? prm.rdir[prm.dir0 + d0] : 0;
+    constexpr int CH = 4;                    // directions whose loads are in flight together
+    int d = d0;
+    while (d < d1) {
+        const int r = prm.rdir[prm.dir0 + d];
+        if (r != rcur) { flush(rcur); rcur = r; }
+        int m = 1;
+        while (m < CH && d + m < d1 && prm.rdir[prm.dir0 + d + m] == r) ++m;
+        T w[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) w[i] = i < m ? prm.dirw[prm.dir0 + d + i] : (T)0;
+        int jy = iy0, jz = iz0;
+        for (size_t e = (size_t)ctx.tid(); e < plane; e += GEN_THREADS) {
+            cx<T> v[CH];
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                v[i] = {(T)0, (T)0};
+                if (i < m) v[i] = prm.p[(size_t)(d + i) * prm.p_bstride + base + e];
+            }
+            cx<T> s = S[jy * LSZ + jz];
+#pragma unroll
+            for (int i = 0; i < CH; ++i) { s.x += w[i] * v[i].x; s.y += w[i] * v[i].y; }
+            S[jy * LSZ + jz] = s;
+            jy += dy; jz += dz;
+            if (jz >= nz) { jz -= nz; ++jy; }
+        }
+        d += m;
+    }
+    if (d0 < d1) flush(rcur);
+    cx<T>* out = prm.slab + (size_t)g * ((size_t)nx * plane) + base;
+    iy = iy0; iz = iz0;
+    for (size_t e = (size_t)ctx.tid(); e < plane; e += GEN_THREADS) {
+        out[e] = Qa[iy * LSZ + iz];
         iy += dy; iz += dz;
         if (iz >= nz) { iz -= nz; ++iy; }
     }
@@ -407,6 +626,15 @@ BFSM_HD void body_gen_acc(const GenAccParams<T>& prm, Ctx& ctx) {
     const int mx = gen_mode(ix, prm.nx), my = gen_mode(iy, prm.ny), mz = gen_mode(iz, prm.nz);
     const int n2 = mx * mx + my * my + mz * mz;
     cx<T> q = prm.first ? cx<T>{(T)0, (T)0} : prm.qhat[idx];
+    if (!prm.dirw) {                          // no weights: the members are slabs of the fused sequence, already weighted
+        for (int d = 0; d < prm.n; ++d) {
+            const cx<T> t = prm.p[(size_t)d * prm.p_bstride + idx];
+            q.x += t.x;
+            q.y += t.y;
+        }
+        prm.qhat[idx] = q;
+        return;
+    }
     for (int d = 0; d < prm.n; ++d) {
         const size_t b = (size_t)(prm.dir0 + d);
         const T w = prm.dirw[b] * prm.beta1[(size_t)prm.rdir[b] * prm.n2stride + n2];
@@ -426,18 +654,27 @@ BFSM_HD void body_gen_combine(const GenCombineParams<T>& prm, Ctx& ctx) {
     prm.Q[idx] = q;
 }
 
-enum class GK { Fft, Acc, Combine, FftBig, Plane };   // FftBig: Fft + the radix-7 / 11 / 13 passes; Plane: y and z pass fused
+enum class GK { Fft, Acc, Combine, FftBig, Plane, Line3, PlaneAcc };   // FftBig: Fft + the radix-7 / 11 / 13 passes; Plane: y and z
+                                                                      // pass fused; Line3 / PlaneAcc: the fused sequence
 
 inline bool gen_factor(int n, std::vector<int>& radix) {
     radix.clear();
     if (n < 2 || n > GEN_MAX_N) return false;
-    while (n % 4 == 0) { radix.push_back(4); n /= 4; }
-    while (n % 2 == 0) { radix.push_back(2); n /= 2; }
+    int k2 = 0;                                    // the power of two goes in the fewest passes of radix 8, 4, 2
+    while (n % 2 == 0) { ++k2; n /= 2; }
+    for (int passes = (k2 + 2) / 3; passes > 0; --passes) {
+        const int bits = (k2 + passes - 1) / passes;
+        radix.push_back(1 << bits);
+        k2 -= bits;
+    }
     while (n % 3 == 0) { radix.push_back(3); n /= 3; }
     while (n % 5 == 0) { radix.push_back(5); n /= 5; }
     for (int r : {7, 11, 13}) while (n % r == 0) { radix.push_back(r); n /= r; }
     return n == 1 && radix.size() <= 8;
 }
+
+// radices served by the table-driven butterflies (GK::FftBig only)
+inline bool gen_table_radix(int r) { return r == 7 || r == 11 || r == 13; }
 
 // grids the generic path serves
 inline bool gen_supported(int nx, int ny, int nz) {
@@ -463,6 +700,8 @@ struct GenericPipeline {
     cx<T>* qhat = nullptr;    // [G]
     cx<T>* tail = nullptr;    // [2][G]: gain, loss
     cx<T>* a = nullptr;       // [2 * chunk][G]: A1, A2 interleaved per direction; P in the even members
+    cx<T>* slab = nullptr;    // fused sequence: [groups][G] partial sums of one chunk
+    int slab_groups = 0;
     cx<T>* tw[3] = {nullptr, nullptr, nullptr};
     cx<T>* phx = nullptr;
     cx<T>* phy = nullptr;
@@ -493,7 +732,8 @@ struct GenericPipeline {
         }
         const long long B = (long long)d.n_gl * d.n_sph;
         plan = PlanInfo();
-        plan.gen_plane = plane_ok();                // exact_reductions / hermitian / antipodal stay false: this path evaluates every
+        plan.gen_plane = plane_ok();
+        plan.gen_fused = fused_ok();                // exact_reductions / hermitian / antipodal stay false: this path evaluates every
         plan.N = 0;                       // direction whatever the flags say (include/bfsm.h documents them as no-ops here)
         plan.Gtot = G;
         plan.precision = d.precision;
@@ -572,15 +812,20 @@ struct GenericPipeline {
         ok = ok && (qhat = (cx<T>*)be->alloc(G * sizeof(cx<T>)));
         ok = ok && (tail = (cx<T>*)be->alloc(2 * G * sizeof(cx<T>)));
         ok = ok && (a = (cx<T>*)be->alloc((size_t)2 * chunk * G * sizeof(cx<T>)));
+        if (fused_ok()) {
+            slab_groups = groups_for(chunk);
+            ok = ok && (slab = (cx<T>*)be->alloc((size_t)slab_groups * G * sizeof(cx<T>)));
+            for (const Chunk& ck : plan.chunks) plan.gen_slabs += groups_for(ck.n);
+        }
         if (!ok) { err = "device allocation failed"; return BFSM_ERR_NOMEM; }
         return BFSM_OK;
     }
 
     void destroy() {
         if (!be) return;
-        void* ptrs[] = {fhat, qhat, tail, a, tw[0], tw[1], tw[2], phx, phy, phz, dirw, rdir, beta1, beta2};
+        void* ptrs[] = {fhat, qhat, tail, a, slab, tw[0], tw[1], tw[2], phx, phy, phz, dirw, rdir, beta1, beta2};
         for (void* p : ptrs) if (p) be->release(p);
-        fhat = qhat = tail = a = phx = phy = phz = nullptr;
+        fhat = qhat = tail = a = slab = phx = phy = phz = nullptr;
         tw[0] = tw[1] = tw[2] = nullptr;
         dirw = beta1 = beta2 = nullptr;
         rdir = nullptr;
@@ -606,9 +851,9 @@ struct GenericPipeline {
         for (int i = 0; i < p.n_radix; ++i) p.radix[i] = radix[axis][i];
         p.mode = mode; p.phx = phx; p.phy = phy; p.phz = phz; p.dir0 = dir0; p.beta2 = beta2;
         p.in_bstride = in_bstride; p.out_bstride = out_bstride;
-        const size_t lds = (size_t)2 * n * (C + 1) * sizeof(cx<T>);
+        const size_t lds = ((size_t)2 * n * (C + 1) + n) * sizeof(cx<T>);
         bool big = false;
-        for (int r : radix[axis]) big = big || r > 5;
+        for (int r : radix[axis]) big = big || gen_table_radix(r);
         if (big) be->template launch_gen<GK::FftBig, T>((ncols + C - 1) / C, batch, GEN_THREADS, lds, p);
         else be->template launch_gen<GK::Fft, T>((ncols + C - 1) / C, batch, GEN_THREADS, lds, p);
     }
@@ -618,7 +863,7 @@ struct GenericPipeline {
 #ifdef BFSM_GEN_NO_PLANE          // A/B builds (tools only): one pass per axis everywhere
         return false;
 #else
-        for (int ax = 1; ax <= 2; ++ax) for (int r : radix[ax]) if (r > 5) return false;
+        for (int ax = 1; ax <= 2; ++ax) for (int r : radix[ax]) if (gen_table_radix(r)) return false;
         // ... and leaves room for four workgroups per CU: with bigger planes the one-pass-per-axis kernels (52 KB at most) win
         // (64 x 48 x 80 in double precision, a 124 KB plane: 0.92 against 1.30 TB/s algorithmic, profiles/r04_generic_ktimes.txt)
         return (size_t)2 * ny * (nz + 1) * sizeof(cx<T>) <= (size_t)40 * 1024 && nz <= GEN_THREADS;
@@ -637,8 +882,60 @@ struct GenericPipeline {
         for (int i = 0; i < p.n_radix_b; ++i) p.radix_b[i] = radix[bsec][i];
         p.mode = mode; p.phx = phx; p.phy = phy; p.phz = phz; p.dir0 = dir0; p.beta2 = beta2;
         p.in_bstride = in_bstride; p.out_bstride = out_bstride;
-        const size_t lds = (size_t)2 * ny * (nz + 1) * sizeof(cx<T>);
+        const size_t lds = ((size_t)2 * ny * (nz + 1) + ny + nz) * sizeof(cx<T>);
         be->template launch_gen<GK::Plane, T>(nx, batch, GEN_THREADS, lds, p);
+    }
+
+    // The fused sequence (plane kernel straight from f_hat, x-line kernel, plane-accumulate kernel: 6 array moves per
+    // direction) serves the boxes of plane_ok() whose x factors are 2, 3, 5 and whose three x-line buffers leave room for
+    // two workgroups per CU.
+    bool fused_ok() const {
+#ifdef BFSM_GEN_NO_FUSE           // A/B builds (tools only): the 12-move sequence
+        return false;
+#else
+        if (!plane_ok()) return false;
+        for (int r : radix[0]) if (gen_table_radix(r)) return false;
+        return (size_t)3 * nx * GEN_LS * sizeof(cx<T>) <= (size_t)80 * 1024;
+#endif
+    }
+    // groups of directions per x-plane in the plane-accumulate kernel: about a thousand workgroups per launch
+    int groups_for(int n) const {
+#ifdef BFSM_GEN_TARGET_WGS        // the emulator build asks for few workgroups, so that its small cases give a group several
+        int g = (BFSM_GEN_TARGET_WGS + nx - 1) / nx;          // directions and runs that cross radial nodes
+#else
+        int g = (1024 + nx - 1) / nx;
+#endif
+        if (g > n) g = n;
+        if (g < 1) g = 1;
+        const int per = (n + g - 1) / g;
+        return per > 0 ? (n + per - 1) / per : 1;
+    }
+    void gain_chunk_fused(const Chunk& c, bool first) {
+        const double Gc = (double)G * sizeof(cx<T>);
+        // A1', A2' = IFFT_yz(alpha f_hat / G), IFFT_yz(conj(alpha) f_hat / G), straight from f_hat (x stays spectral)
+        be->mark(BFSM_K_GAIN_INV, 2.0 * c.n * Gc);
+        plane(fhat, nullptr, a, 2 * c.n, +1, GEN_PHASE, 0, G, c.dir0);
+        GenLineParams<T> kl{};
+        kl.a = a; kl.tw = tw[0]; kl.nx = nx; kl.ny = ny; kl.nz = nz;
+        kl.n_radix = (int)radix[0].size();
+        for (int i = 0; i < kl.n_radix; ++i) kl.radix[i] = radix[0][i];
+        const int ncols = ny * nz;
+        be->mark(BFSM_K_GAIN_LINE, 3.0 * c.n * Gc);
+        be->template launch_gen<GK::Line3, T>((ncols + GEN_C - 1) / GEN_C, c.n, GEN_THREADS, ((size_t)3 * nx * GEN_LS + nx) * sizeof(cx<T>), kl);
+        GenPlaneAccParams<T> kp{};
+        const int groups = groups_for(c.n);
+        kp.p = a; kp.p_bstride = 2 * G; kp.slab = slab; kp.dirw = dirw; kp.rdir = rdir; kp.beta1 = beta1;
+        kp.dir0 = c.dir0; kp.n = c.n; kp.per_group = (c.n + groups - 1) / groups; kp.n2stride = n2stride;
+        kp.nx = nx; kp.ny = ny; kp.nz = nz; kp.tw = tw[2]; kp.tw_b = tw[1];
+        kp.n_radix = (int)radix[2].size(); kp.n_radix_b = (int)radix[1].size();
+        for (int i = 0; i < kp.n_radix; ++i) kp.radix[i] = radix[2][i];
+        for (int i = 0; i < kp.n_radix_b; ++i) kp.radix_b[i] = radix[1][i];
+        be->mark(BFSM_K_GAIN_FWD, (1.0 * c.n + groups) * Gc);
+        be->template launch_gen<GK::PlaneAcc, T>(nx, groups, GEN_THREADS, ((size_t)3 * ny * (nz + 1) + ny + nz) * sizeof(cx<T>), kp);
+        // Q_hat (+)= the groups' slabs, fixed order
+        GenAccParams<T> ka{slab, G, qhat, nullptr, nullptr, nullptr, 0, groups, n2stride, first ? 1 : 0, nx, ny, nz};
+        be->mark(BFSM_K_REDUCE, (groups + (first ? 1.0 : 2.0)) * Gc);
+        be->template launch_gen<GK::Acc, T>((int)((G + GEN_THREADS - 1) / GEN_THREADS), 1, GEN_THREADS, 0, ka);
     }
 
     // f_hat = FFT(f), then the gain term of this shard into qhat   (CUDABoltzmannOperator.cu:131-191)
@@ -654,7 +951,9 @@ struct GenericPipeline {
         }
         be->mark(BFSM_K_FFT_F, 2.0 * Gc); pass(fhat, nullptr, fhat, 1, 0, -1, GEN_PLAIN, 0, 0);
         bool first = true;
+        const bool fused = fused_ok();
         for (const Chunk& c : plan.chunks) {
+            if (fused) { gain_chunk_fused(c, first); first = false; continue; }
             const int nb2 = 2 * c.n;
             // A1, A2 = IFFT(alpha f_hat / G), IFFT(conj(alpha) f_hat / G): members 2d, 2d + 1 of `a`
             // accounting: the SURVEY 8(d) model attributes 2 array passes per direction to this group (the inverse

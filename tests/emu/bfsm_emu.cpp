@@ -250,6 +250,8 @@ struct EmuBackend {
     else if constexpr (kind == bfsm::GK::Plane) bfsm::body_gen_plane<T>(prm, ctx);
         else if constexpr (kind == bfsm::GK::Acc) bfsm::body_gen_acc<T>(prm, ctx);
         else if constexpr (kind == bfsm::GK::Combine) bfsm::body_gen_combine<T>(prm, ctx);
+        else if constexpr (kind == bfsm::GK::Line3) bfsm::body_gen_line3<T>(prm, ctx);
+        else if constexpr (kind == bfsm::GK::PlaneAcc) bfsm::body_gen_plane_acc<T>(prm, ctx);
     }
 
     template <bfsm::GK kind, typename T, class P>
