@@ -207,8 +207,9 @@ BFSM_HD void gen_stage_tw(cx<T>* dst, const cx<T>* tw, int n, Ctx& ctx) {
     for (int i = ctx.tid(); i < n; i += GEN_THREADS) dst[i] = tw[i];
 }
 
-template <int R, bool NS_POW2, typename T, class Ctx>
-BFSM_HD void gen_pass(const cx<T>* src, cx<T>* dst, const cx<T>* tw, int n, int ns, int sgn, Ctx& ctx) {
+// FIRST: the pass with ns = 1, whose twiddles are all 1 (k = 0): no table reads, no multiplications.
+template <int R, bool NS_POW2, bool FIRST, typename T, class Ctx>
+BFSM_HD void gen_pass_impl(const cx<T>* src, cx<T>* dst, const cx<T>* tw, int n, int ns, int sgn, Ctx& ctx) {
     const int m = n / R;
     const int col = ctx.tid() % GEN_C, row = ctx.tid() / GEN_C;
     const int tstep = n / (ns * R);                    // twiddle exp(sgn 2 pi i k q / (ns R)) = tw[k q tstep], k q tstep < n
@@ -220,7 +221,7 @@ BFSM_HD void gen_pass(const cx<T>* src, cx<T>* dst, const cx<T>* tw, int n, int 
 #pragma unroll
         for (int q = 0; q < R; ++q) {
             x[q] = src[(j + q * m) * GEN_LS + col];
-            if (q > 0) {
+            if (!FIRST && q > 0) {
                 const cx<T> w = tw[k * q * tstep];
                 x[q] = sgn < 0 ? cmul(x[q], w) : cmulc(x[q], w);
             }
@@ -231,6 +232,11 @@ BFSM_HD void gen_pass(const cx<T>* src, cx<T>* dst, const cx<T>* tw, int n, int 
 #pragma unroll
         for (int q = 0; q < R; ++q) dst[(j0 + q * ns) * GEN_LS + col] = x[q];
     }
+}
+template <int R, bool NS_POW2, typename T, class Ctx>
+BFSM_HD void gen_pass(const cx<T>* src, cx<T>* dst, const cx<T>* tw, int n, int ns, int sgn, Ctx& ctx) {
+    // (the twiddle-free instantiation pays in the plane kernels only: with it the x-line kernel measured 7 % slower)
+    gen_pass_impl<R, NS_POW2, false, T>(src, dst, tw, n, ns, sgn, ctx);
 }
 
 // Batched 1-D transform along one axis.  grid = (blocks of GEN_C lines, batch).  Workgroup: GEN_THREADS threads, LDS =
@@ -348,8 +354,8 @@ BFSM_HD void body_gen_fft(const GenFftParams<T>& prm, Ctx& ctx) {
 // One Stockham pass of radix R over ALL nl lines of n points of a plane held in LDS; element (point pt, line l) at
 // pt * ps + l * ls.  The nl * n / R butterflies are dealt to the threads as one flat range, lanes along the lines (unit or
 // odd stride in LDS either way), so that every thread works whenever the plane has 256 butterflies to give.
-template <int R, bool NS_POW2, typename T, class Ctx>
-BFSM_HD void gen_plane_pass(const cx<T>* src, cx<T>* dst, const cx<T>* tw, int n, int ns, int sgn, int nl, int ps, int ls, Ctx& ctx) {
+template <int R, bool NS_POW2, bool FIRST, typename T, class Ctx>
+BFSM_HD void gen_plane_pass_impl(const cx<T>* src, cx<T>* dst, const cx<T>* tw, int n, int ns, int sgn, int nl, int ps, int ls, Ctx& ctx) {
     const int m = n / R;
     const int tstep = n / (ns * R);
     const int sh = NS_POW2 ? (31 - __builtin_clz((unsigned)ns)) : 0;
@@ -364,7 +370,7 @@ BFSM_HD void gen_plane_pass(const cx<T>* src, cx<T>* dst, const cx<T>* tw, int n
 #pragma unroll
         for (int q = 0; q < R; ++q) {
             x[q] = s0[(j + q * m) * ps];
-            if (q > 0) {
+            if (!FIRST && q > 0) {
                 const cx<T> wq = tw[k * q * tstep];
                 x[q] = sgn < 0 ? cmul(x[q], wq) : cmulc(x[q], wq);
             }
@@ -374,6 +380,11 @@ BFSM_HD void gen_plane_pass(const cx<T>* src, cx<T>* dst, const cx<T>* tw, int n
 #pragma unroll
         for (int q = 0; q < R; ++q) d0[(j0 + q * ns) * ps] = x[q];
     }
+}
+template <int R, bool NS_POW2, typename T, class Ctx>
+BFSM_HD void gen_plane_pass(const cx<T>* src, cx<T>* dst, const cx<T>* tw, int n, int ns, int sgn, int nl, int ps, int ls, Ctx& ctx) {
+    if (ns == 1) gen_plane_pass_impl<R, true, true, T>(src, dst, tw, n, ns, sgn, nl, ps, ls, ctx);
+    else gen_plane_pass_impl<R, NS_POW2, false, T>(src, dst, tw, n, ns, sgn, nl, ps, ls, ctx);
 }
 
 template <typename T, class Ctx>
@@ -733,7 +744,8 @@ struct GenericPipeline {
         const long long B = (long long)d.n_gl * d.n_sph;
         plan = PlanInfo();
         plan.gen_plane = plane_ok();
-        plan.gen_fused = fused_ok();                // exact_reductions / hermitian / antipodal stay false: this path evaluates every
+        plan.gen_fused = fused_ok();
+        plan.gen_moves = fused_ok() ? 6 : (line3_ok((size_t)150 * 1024) ? (plane_ok() ? 8 : 14) : (plane_ok() ? 12 : 18));                // exact_reductions / hermitian / antipodal stay false: this path evaluates every
         plan.N = 0;                       // direction whatever the flags say (include/bfsm.h documents them as no-ops here)
         plan.Gtot = G;
         plan.precision = d.precision;
@@ -893,10 +905,27 @@ struct GenericPipeline {
 #ifdef BFSM_GEN_NO_FUSE           // A/B builds (tools only): the 12-move sequence
         return false;
 #else
-        if (!plane_ok()) return false;
-        for (int r : radix[0]) if (gen_table_radix(r)) return false;
-        return (size_t)3 * nx * GEN_LS * sizeof(cx<T>) <= (size_t)80 * 1024;
+        return plane_ok() && line3_ok((size_t)80 * 1024);
 #endif
+    }
+    // the x-line kernel alone (both inverse x passes, the product and the forward x pass in one: 4 array moves fewer) also
+    // serves boxes whose plane does not fit, as long as its three line buffers fit the CU
+    bool line3_ok(size_t lds_cap) const {
+#ifdef BFSM_GEN_NO_FUSE
+        return false;
+#else
+        for (int r : radix[0]) if (gen_table_radix(r)) return false;
+        return ((size_t)3 * nx * GEN_LS + nx) * sizeof(cx<T>) <= lds_cap;
+#endif
+    }
+    void line3(const Chunk& c) {
+        GenLineParams<T> kl{};
+        kl.a = a; kl.tw = tw[0]; kl.nx = nx; kl.ny = ny; kl.nz = nz;
+        kl.n_radix = (int)radix[0].size();
+        for (int i = 0; i < kl.n_radix; ++i) kl.radix[i] = radix[0][i];
+        const int ncols = ny * nz;
+        be->mark(BFSM_K_GAIN_LINE, 3.0 * c.n * (double)G * sizeof(cx<T>));
+        be->template launch_gen<GK::Line3, T>((ncols + GEN_C - 1) / GEN_C, c.n, GEN_THREADS, ((size_t)3 * nx * GEN_LS + nx) * sizeof(cx<T>), kl);
     }
     // groups of directions per x-plane in the plane-accumulate kernel: about a thousand workgroups per launch
     int groups_for(int n) const {
@@ -915,13 +944,7 @@ struct GenericPipeline {
         // A1', A2' = IFFT_yz(alpha f_hat / G), IFFT_yz(conj(alpha) f_hat / G), straight from f_hat (x stays spectral)
         be->mark(BFSM_K_GAIN_INV, 2.0 * c.n * Gc);
         plane(fhat, nullptr, a, 2 * c.n, +1, GEN_PHASE, 0, G, c.dir0);
-        GenLineParams<T> kl{};
-        kl.a = a; kl.tw = tw[0]; kl.nx = nx; kl.ny = ny; kl.nz = nz;
-        kl.n_radix = (int)radix[0].size();
-        for (int i = 0; i < kl.n_radix; ++i) kl.radix[i] = radix[0][i];
-        const int ncols = ny * nz;
-        be->mark(BFSM_K_GAIN_LINE, 3.0 * c.n * Gc);
-        be->template launch_gen<GK::Line3, T>((ncols + GEN_C - 1) / GEN_C, c.n, GEN_THREADS, ((size_t)3 * nx * GEN_LS + nx) * sizeof(cx<T>), kl);
+        line3(c);
         GenPlaneAccParams<T> kp{};
         const int groups = groups_for(c.n);
         kp.p = a; kp.p_bstride = 2 * G; kp.slab = slab; kp.dirw = dirw; kp.rdir = rdir; kp.beta1 = beta1;
@@ -951,10 +974,32 @@ struct GenericPipeline {
         }
         be->mark(BFSM_K_FFT_F, 2.0 * Gc); pass(fhat, nullptr, fhat, 1, 0, -1, GEN_PLAIN, 0, 0);
         bool first = true;
-        const bool fused = fused_ok();
+        const bool fused = fused_ok(), l3 = line3_ok((size_t)150 * 1024);
         for (const Chunk& c : plan.chunks) {
             if (fused) { gain_chunk_fused(c, first); first = false; continue; }
             const int nb2 = 2 * c.n;
+            if (l3) {
+                // the (y,z) passes of the inverse transforms first (phase factors on the load side, straight from f_hat), then
+                // the x-line kernel, then the (y,z) passes of the forward transform: 14 array moves (8 with the plane kernel)
+                be->mark(BFSM_K_GAIN_INV, 2.0 * c.n * Gc);
+                if (pl) plane(fhat, nullptr, a, nb2, +1, GEN_PHASE, 0, G, c.dir0);
+                else {
+                    pass(fhat, nullptr, a, nb2, 2, +1, GEN_PHASE, 0, G, c.dir0);
+                    be->mark(BFSM_K_GAIN_INV, 0); pass(a, nullptr, a, nb2, 1, +1, GEN_PLAIN, G, G);
+                }
+                line3(c);
+                be->mark(BFSM_K_GAIN_LINE, 0);
+                if (pl) plane(a, nullptr, a, c.n, -1, GEN_PLAIN, 2 * G, 2 * G);
+                else {
+                    pass(a, nullptr, a, c.n, 1, -1, GEN_PLAIN, 2 * G, 2 * G);
+                    be->mark(BFSM_K_GAIN_LINE, 0); pass(a, nullptr, a, c.n, 2, -1, GEN_PLAIN, 2 * G, 2 * G);
+                }
+                GenAccParams<T> ka{a, 2 * G, qhat, dirw, rdir, beta1, c.dir0, c.n, n2stride, first ? 1 : 0, nx, ny, nz};
+                be->mark(BFSM_K_GAIN_FWD, 1.0 * c.n * Gc);
+                be->template launch_gen<GK::Acc, T>((int)((G + GEN_THREADS - 1) / GEN_THREADS), 1, GEN_THREADS, 0, ka);
+                first = false;
+                continue;
+            }
             // A1, A2 = IFFT(alpha f_hat / G), IFFT(conj(alpha) f_hat / G): members 2d, 2d + 1 of `a`
             // accounting: the SURVEY 8(d) model attributes 2 array passes per direction to this group (the inverse
             // transforms), 3 to the next (product + forward transform) and 1 to the accumulate; the path moves more

@@ -54,6 +54,7 @@ struct PlanInfo {
     bool gen_plane = false;                // size-generic path: y and z pass fused through LDS (12 instead of 18 array moves)
     bool gen_fused = false;                // size-generic path: plane / x-line / plane-accumulate kernels (6 array moves)
     int gen_slabs = 0;                     // ... and the partial-sum slabs its chunks write
+    int gen_moves = 18;                    // size-generic path: array moves per direction of the sequence chosen (6 ... 18)
     size_t G() const { return Gtot ? Gtot : (size_t)N * N * N; }
     long long n_dirs() const { return dir_end - dir_begin; }
 };
@@ -557,8 +558,7 @@ inline double moved_bytes_per_eval(const PlanInfo& p) {
     const double c = p.precision == BFSM_F64 ? 16.0 : 8.0;
     const double G = (double)p.G(), n = (double)p.n_dirs(), sg = (double)p.segs.size();
     // size-generic path: one pass per axis (or x + a fused (y,z) plane pass), pointwise steps fused on the load side
-    if (p.N == 0 && p.gen_fused) return (6.0 * n + 2.0 * p.gen_slabs + 18.0) * G * c;
-    if (p.N == 0) return p.gen_plane ? (12.0 * n + 18.0) * G * c : (18.0 * n + 27.0) * G * c;
+    if (p.N == 0) return ((double)p.gen_moves * n + 2.0 * p.gen_slabs + (p.gen_plane ? 18.0 : 27.0)) * G * c;
     if (!p.exact_reductions) return (6.0 * n + 2.0 * sg + 9.0) * G * c;
     const double h = p.hermitian ? (double)(p.N / 2 + 1) / p.N : 1.0;
     return (4.0 * n * h + 4.0 * sg + 9.0) * G * c;

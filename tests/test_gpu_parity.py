@@ -965,7 +965,11 @@ def _make_box(bfsm, shape, n_gl, n_sph, precision=64, shard=None, max_chunk=0, g
 @pytest.mark.parametrize("shape,n_gl,n_sph,max_chunk", [((32, 64, 16), 4, 12, 0), ((48, 48, 48), 4, 12, 0),
                                                         ((96, 96, 96), 2, 6, 0), ((64, 48, 80), 2, 12, 5),
                                                         ((16, 128, 32), 3, 6, 0), ((20, 36, 50), 3, 12, 7),
-                                                        ((28, 22, 26), 2, 6, 0), ((112, 14, 8), 2, 6, 0)])
+                                                        ((28, 22, 26), 2, 6, 0), ((112, 14, 8), 2, 6, 0),
+                                                        # fused sequence, groups of 4 directions across radial nodes
+                                                        ((96, 8, 10), 6, 6, 0),
+                                                        # x-line kernel between plane kernels / between per-axis passes
+                                                        ((128, 8, 8), 5, 6, 0), ((16, 28, 12), 2, 6, 0)])
 def test_any_box_matches_oracle(torch_cuda, oracle, shape, n_gl, n_sph, max_chunk):
     """Grid generality of the reference's constructors (CUDABoltzmannOperator.hpp:48-54; plans cu:86-100): non-cubic
     boxes and sizes with factors 3 and 5 match the oracle at the fp64 tolerance (the cubes 48^3 and 96^3 on the fused
