@@ -3,15 +3,19 @@
 // (Collisions/CUDABoltzmannOperator.cu:86-100) and fftw_plan_dft_3d (Collisions/FFTWBoltzmannOperator.cpp:64-65).
 //
 // The cubic grids N in {16, 24, 32, 40, 48, 64, 80, 96, 128} run on the fused three-kernel pipeline of bfsm_core.hpp (6 array passes
-// per direction); everything else runs here: one batched 1-D mixed-radix Stockham pass per axis, transformed in LDS, with
-// the pointwise steps of the reference fused into the pass that touches the data first
-//     phase multiply (compute_alpha_times_f_hat, BoltzmannCUDAKernels.cu:21-59)  -> load side of the first inverse pass
-//     hadamard_product (Kernels.cu:62-74)                                        -> load side of the first forward pass
-//     beta2 * f_hat (Kernels.cu:126-159)                                         -> load side of the first tail pass
-//     copy_to_complex (Kernels.cu:4-16)                                          -> load side of the first pass of FFT(f)
-// and a deterministic, atomic-free accumulate (atomic_tensor_contraction, Kernels.cu:79-123).  18 array moves per
-// direction instead of 6: a correct fallback for every size (measured 1.2-1.4 TB/s algorithmic), not a tuned path.  Layouts are the reference's own: physical
-// [x][y][z], spectral [lx][ly][lz], z contiguous.
+// per direction); everything else runs here, on mixed-radix (8, 4, 2, 3, 5; 7, 11, 13 table-driven) Stockham passes in LDS
+// with runtime sizes.  Three sequences, chosen per box in GenericPipeline (profiles/r04_generic_fused_ab.txt):
+//   * the (y,z) plane fits the LDS (most boxes up to ~1300 plane points in double precision): the cubic pipeline's three
+//     kernels in size-generic form -- body_gen_plane straight from f_hat with the phase multiply on its load side
+//     (compute_alpha_times_f_hat, BoltzmannCUDAKernels.cu:21-59), body_gen_line3 (x part of both inverse transforms,
+//     hadamard_product Kernels.cu:62-74, x part of the forward transform), body_gen_plane_acc ((y,z) forward transform +
+//     atomic-free accumulate, Kernels.cu:79-123) -- 6 array moves per direction, 2.2-2.6 TB/s algorithmic;
+//   * bigger planes: per-axis passes with the x-line kernel in the middle, 14 moves (8 where only the x lines are too long
+//     for the first form);
+//   * x axes with a factor 7, 11 or 13: one pass per axis (or x + a plane pass), 18 / 12 moves.
+// The other pointwise steps ride on load sides as before: beta2 * f_hat (Kernels.cu:126-159) on the first tail pass,
+// copy_to_complex (Kernels.cu:4-16) on the first pass of FFT(f).  Layouts are the reference's own: physical [x][y][z],
+// spectral [lx][ly][lz], z contiguous.
 //
 // Like bfsm_core.hpp the kernel bodies are templates over an execution context, so tests/emu runs the same code on the
 // host.
