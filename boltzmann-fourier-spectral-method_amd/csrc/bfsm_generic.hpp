@@ -62,6 +62,10 @@ struct GenFftParams {
     const cx<T>* tw_b;
     int n_radix_b;
     int radix_b[8];
+    // batches of distributions evaluated together: grid.y = members x mper, member m at + m * in_mstride / out_mstride and the
+    // index inside the member (what the fusions above call b) = grid.y index mod mper.  mper = 0: no member level.
+    int mper;
+    size_t in_mstride, out_mstride;
 };
 
 template <typename T>
@@ -77,6 +81,7 @@ struct GenAccParams {        // Q_hat[l] (+)= sum_d dirw[d] beta1[r(d)][|l|^2] P
     int n2stride;
     int first;               // != 0: start from zero instead of from qhat
     int nx, ny, nz;
+    size_t p_mstride, q_mstride;   // grid.y = members
 };
 
 // Fused sequence of the boxes whose (y,z) plane fits the LDS (round 4): the three kernels of the cubic pipeline in
@@ -88,6 +93,8 @@ struct GenLineParams {       // x part of both inverse transforms + product + x 
     int nx, ny, nz;
     int n_radix;
     int radix[8];
+    int n;                   // directions of the chunk: grid.y = members x n
+    size_t mstride;          // elements between the members' scratch
 };
 
 template <typename T>
@@ -107,6 +114,8 @@ struct GenPlaneAccParams {   // (y,z) part of the forward transform + weighted s
     const cx<T>* tw_b;
     int n_radix, n_radix_b;
     int radix[8], radix_b[8];
+    int groups;              // grid.y = members x groups
+    size_t p_mstride;        // elements between the members' scratch; member m's slabs at slab + m * groups * G
 };
 
 template <typename T>
@@ -256,7 +265,14 @@ BFSM_HD void body_gen_fft(const GenFftParams<T>& prm, Ctx& ctx) {
     const int n = axis == 0 ? nx : (axis == 1 ? ny : nz);
     const size_t G = (size_t)nx * ny * nz;
     const int ncols = (int)(G / (size_t)n);
-    const int b = ctx.by();
+    int b = ctx.by();
+    size_t in_moff = 0, out_moff = 0;
+    if (prm.mper > 0) {
+        const int m = b / prm.mper;
+        b -= m * prm.mper;
+        in_moff = (size_t)m * prm.in_mstride;
+        out_moff = (size_t)m * prm.out_mstride;
+    }
     cx<T>* buf0 = ctx.template lds<cx<T>>();
     cx<T>* buf1 = buf0 + (size_t)n * GEN_LS;
     cx<T>* twl = buf1 + (size_t)n * GEN_LS;
@@ -274,7 +290,7 @@ BFSM_HD void body_gen_fft(const GenFftParams<T>& prm, Ctx& ctx) {
     if (axis == 0) { base = (size_t)col; ps = (size_t)ny * nz; i0y = col / nz; i0z = col - i0y * nz; }
     else if (axis == 1) { i0x = col / nz; i0z = col - i0x * nz; base = (size_t)i0x * ny * nz + i0z; ps = (size_t)nz; }
     else { i0x = col / ny; i0y = col - i0x * ny; base = (size_t)col * nz; ps = 1; }
-    const size_t in_off = (size_t)b * prm.in_bstride;
+    const size_t in_off = in_moff + (size_t)b * prm.in_bstride;
     // GEN_PHASE: the factors of the two axes that are NOT transformed are constant along the line: one product per thread,
     // then one table value and two complex multiplications per point instead of three and three
     cx<T> ph_line = {(T)1, (T)0};
@@ -350,7 +366,7 @@ BFSM_HD void body_gen_fft(const GenFftParams<T>& prm, Ctx& ctx) {
         cx<T>* t = src; src = dst; dst = t;
     }
     if (live) {
-        const size_t out_off = (size_t)b * prm.out_bstride;
+        const size_t out_off = out_moff + (size_t)b * prm.out_bstride;
         for (int pt = p0; pt < n; pt += GEN_THREADS / GEN_C) prm.out[out_off + base + (size_t)pt * ps] = src[pt * GEN_LS + cl];
     }
 }
@@ -418,7 +434,15 @@ BFSM_HD void gen_plane_axis(cx<T>*& src, cx<T>*& dst, const cx<T>* tw, const int
 template <typename T, class Ctx>
 BFSM_HD void body_gen_plane(const GenFftParams<T>& prm, Ctx& ctx) {
     const int nx = prm.nx, ny = prm.ny, nz = prm.nz;
-    const int ix = ctx.bx(), b = ctx.by();
+    const int ix = ctx.bx();
+    int b = ctx.by();
+    size_t in_moff = 0, out_moff = 0;
+    if (prm.mper > 0) {
+        const int m = b / prm.mper;
+        b -= m * prm.mper;
+        in_moff = (size_t)m * prm.in_mstride;
+        out_moff = (size_t)m * prm.out_mstride;
+    }
     const int LSZ = nz + 1;                                  // LDS row stride of the plane (odd: conflict-free both ways)
     cx<T>* buf0 = ctx.template lds<cx<T>>();
     cx<T>* buf1 = buf0 + (size_t)ny * LSZ;
@@ -427,7 +451,7 @@ BFSM_HD void body_gen_plane(const GenFftParams<T>& prm, Ctx& ctx) {
     gen_stage_tw<T>(twa, prm.tw, prm.sign < 0 ? nz : ny, ctx);
     gen_stage_tw<T>(twb, prm.tw_b, prm.sign < 0 ? ny : nz, ctx);
     const size_t plane = (size_t)ny * nz, base = (size_t)ix * plane;
-    const size_t in_off = (size_t)b * prm.in_bstride;
+    const size_t in_off = in_moff + (size_t)b * prm.in_bstride;
     // (iy, iz) of the element this thread touches, advanced by GEN_THREADS elements per step without a division
     const int dy = GEN_THREADS / nz, dz = GEN_THREADS - dy * nz;
     int iy = ctx.tid() / nz, iz = ctx.tid() - iy * nz;
@@ -461,7 +485,7 @@ BFSM_HD void body_gen_plane(const GenFftParams<T>& prm, Ctx& ctx) {
         gen_plane_axis<T>(src, dst, twa, prm.radix, prm.n_radix, ny, prm.sign, nz, LSZ, 1, ctx);
         gen_plane_axis<T>(src, dst, twb, prm.radix_b, prm.n_radix_b, nz, prm.sign, ny, 1, LSZ, ctx);
     }
-    const size_t out_off = (size_t)b * prm.out_bstride;
+    const size_t out_off = out_moff + (size_t)b * prm.out_bstride;
     iy = ctx.tid() / nz; iz = ctx.tid() - iy * nz;
     for (size_t e = (size_t)ctx.tid(); e < plane; e += GEN_THREADS) {
         prm.out[out_off + base + e] = src[iy * LSZ + iz];
@@ -505,7 +529,8 @@ BFSM_HD void body_gen_line3(const GenLineParams<T>& prm, Ctx& ctx) {
     const int cl = ctx.tid() % GEN_C, p0 = ctx.tid() / GEN_C;
     const size_t col = (size_t)ctx.bx() * GEN_C + cl;
     const bool live = col < ps;
-    cx<T>* A1 = prm.a + (size_t)ctx.by() * 2 * G + col;
+    const int mem = ctx.by() / prm.n, dl = ctx.by() - mem * prm.n;
+    cx<T>* A1 = prm.a + (size_t)mem * prm.mstride + (size_t)dl * 2 * G + col;
     const cx<T>* A2 = A1 + G;
     constexpr int STEP = GEN_THREADS / GEN_C, CH = 4;
     for (int pc = p0; pc < n; pc += CH * STEP) {
@@ -547,7 +572,7 @@ BFSM_HD void body_gen_line3(const GenLineParams<T>& prm, Ctx& ctx) {
 template <typename T, class Ctx>
 BFSM_HD void body_gen_plane_acc(const GenPlaneAccParams<T>& prm, Ctx& ctx) {
     const int nx = prm.nx, ny = prm.ny, nz = prm.nz;
-    const int ix = ctx.bx(), g = ctx.by();
+    const int ix = ctx.bx(), mem = ctx.by() / prm.groups, g = ctx.by() - mem * prm.groups;
     const int LSZ = nz + 1;
     cx<T>* S = ctx.template lds<cx<T>>();
     cx<T>* W = S + (size_t)ny * LSZ;
@@ -591,6 +616,7 @@ BFSM_HD void body_gen_plane_acc(const GenPlaneAccParams<T>& prm, Ctx& ctx) {
         }
         ctx.sync();                          // src may be W: the next run's transform overwrites it
     };
+    const cx<T>* pm = prm.p + (size_t)mem * prm.p_mstride;
     const int d0 = g * prm.per_group;
     int d1 = d0 + prm.per_group;
     if (d1 > prm.n) d1 = prm.n;
@@ -611,7 +637,7 @@ BFSM_HD void body_gen_plane_acc(const GenPlaneAccParams<T>& prm, Ctx& ctx) {
 #pragma unroll
             for (int i = 0; i < CH; ++i) {
                 v[i] = {(T)0, (T)0};
-                if (i < m) v[i] = prm.p[(size_t)(d + i) * prm.p_bstride + base + e];
+                if (i < m) v[i] = pm[(size_t)(d + i) * prm.p_bstride + base + e];
             }
             cx<T> s = S[jy * LSZ + jz];
 #pragma unroll
@@ -623,7 +649,7 @@ BFSM_HD void body_gen_plane_acc(const GenPlaneAccParams<T>& prm, Ctx& ctx) {
         d += m;
     }
     if (d0 < d1) flush(rcur);
-    cx<T>* out = prm.slab + (size_t)g * ((size_t)nx * plane) + base;
+    cx<T>* out = prm.slab + ((size_t)mem * prm.groups + g) * ((size_t)nx * plane) + base;
     iy = iy0; iz = iz0;
     for (size_t e = (size_t)ctx.tid(); e < plane; e += GEN_THREADS) {
         out[e] = Qa[iy * LSZ + iz];
@@ -640,24 +666,26 @@ BFSM_HD void body_gen_acc(const GenAccParams<T>& prm, Ctx& ctx) {
     const int iz = (int)(idx % prm.nz), iy = (int)((idx / prm.nz) % prm.ny), ix = (int)(idx / ((size_t)prm.nz * prm.ny));
     const int mx = gen_mode(ix, prm.nx), my = gen_mode(iy, prm.ny), mz = gen_mode(iz, prm.nz);
     const int n2 = mx * mx + my * my + mz * mz;
-    cx<T> q = prm.first ? cx<T>{(T)0, (T)0} : prm.qhat[idx];
+    const cx<T>* pp = prm.p + (size_t)ctx.by() * prm.p_mstride;
+    cx<T>* qh = prm.qhat + (size_t)ctx.by() * prm.q_mstride;
+    cx<T> q = prm.first ? cx<T>{(T)0, (T)0} : qh[idx];
     if (!prm.dirw) {                          // no weights: the members are slabs of the fused sequence, already weighted
         for (int d = 0; d < prm.n; ++d) {
-            const cx<T> t = prm.p[(size_t)d * prm.p_bstride + idx];
+            const cx<T> t = pp[(size_t)d * prm.p_bstride + idx];
             q.x += t.x;
             q.y += t.y;
         }
-        prm.qhat[idx] = q;
+        qh[idx] = q;
         return;
     }
     for (int d = 0; d < prm.n; ++d) {
         const size_t b = (size_t)(prm.dir0 + d);
         const T w = prm.dirw[b] * prm.beta1[(size_t)prm.rdir[b] * prm.n2stride + n2];
-        const cx<T> t = prm.p[(size_t)d * prm.p_bstride + idx];
+        const cx<T> t = pp[(size_t)d * prm.p_bstride + idx];
         q.x += w * t.x;
         q.y += w * t.y;
     }
-    prm.qhat[idx] = q;
+    qh[idx] = q;
 }
 
 template <typename T, class Ctx>
@@ -760,9 +788,11 @@ struct GenericPipeline {
         const long long nd = plan.n_dirs();
         // directions resident at once: bounded by max_chunk (default 256) and by 8 GiB of A1 / A2 scratch
         long long c = d.max_chunk > 0 ? d.max_chunk : 256;
-        const long long by_mem = (long long)((8.0 * 1024 * 1024 * 1024) / (2.0 * (double)G * sizeof(cx<T>)));
+        const bool together = max_batch > 1 && batch_together();      // every member has its own scratch then
+        const int mb = together ? max_batch : 1;
+        const long long by_mem = (long long)((8.0 * 1024 * 1024 * 1024) / (2.0 * (double)G * sizeof(cx<T>) * mb));
         if (c > by_mem) c = by_mem;
-        if (c > 32767) c = 32767;           // 2 * chunk is a grid dimension
+        if (c > 32767 / mb) c = 32767 / mb;   // members x 2 x chunk is a grid dimension
         if (c > nd) c = nd;
         if (c < 1) c = 1;
         chunk = (int)c;
@@ -824,13 +854,13 @@ struct GenericPipeline {
         }
         ok = ok && dev_copy(phx, hx_) && dev_copy(phy, hy_) && dev_copy(phz, hz_) && dev_copy(dirw, hw) && dev_copy(rdir, hr);
         ok = ok && dev_copy(beta1, b1) && dev_copy(beta2, b2v);
-        ok = ok && (fhat = (cx<T>*)be->alloc(G * sizeof(cx<T>)));
-        ok = ok && (qhat = (cx<T>*)be->alloc(G * sizeof(cx<T>)));
-        ok = ok && (tail = (cx<T>*)be->alloc(2 * G * sizeof(cx<T>)));
-        ok = ok && (a = (cx<T>*)be->alloc((size_t)2 * chunk * G * sizeof(cx<T>)));
+        ok = ok && (fhat = (cx<T>*)be->alloc((size_t)mb * G * sizeof(cx<T>)));
+        ok = ok && (qhat = (cx<T>*)be->alloc((size_t)mb * G * sizeof(cx<T>)));
+        ok = ok && (tail = (cx<T>*)be->alloc((size_t)2 * max_batch * G * sizeof(cx<T>)));
+        ok = ok && (a = (cx<T>*)be->alloc((size_t)mb * 2 * chunk * G * sizeof(cx<T>)));
         if (fused_ok()) {
             slab_groups = groups_for(chunk);
-            ok = ok && (slab = (cx<T>*)be->alloc((size_t)slab_groups * G * sizeof(cx<T>)));
+            ok = ok && (slab = (cx<T>*)be->alloc((size_t)mb * slab_groups * G * sizeof(cx<T>)));
             for (const Chunk& ck : plan.chunks) plan.gen_slabs += groups_for(ck.n);
         }
         if (!ok) { err = "device allocation failed"; return BFSM_ERR_NOMEM; }
@@ -886,8 +916,9 @@ struct GenericPipeline {
 #endif
     }
     void plane(const void* in, const cx<T>* in2, cx<T>* out, int batch, int sign, int mode, size_t in_bstride, size_t out_bstride,
-               long long dir0 = 0) {
+               long long dir0 = 0, int mper = 0, size_t in_mstride = 0, size_t out_mstride = 0) {
         GenFftParams<T> p{};
+        p.mper = mper; p.in_mstride = in_mstride; p.out_mstride = out_mstride;
         p.in = in; p.in2 = in2; p.out = out;
         p.nx = nx; p.ny = ny; p.nz = nz; p.axis = 1; p.sign = sign; p.C = GEN_C;
         const int a = sign < 0 ? 2 : 1, bsec = sign < 0 ? 1 : 2;          // first / second axis transformed
@@ -922,14 +953,15 @@ struct GenericPipeline {
         return ((size_t)3 * nx * GEN_LS + nx) * sizeof(cx<T>) <= lds_cap;
 #endif
     }
-    void line3(const Chunk& c) {
+    void line3(const Chunk& c, int nb = 1) {
         GenLineParams<T> kl{};
         kl.a = a; kl.tw = tw[0]; kl.nx = nx; kl.ny = ny; kl.nz = nz;
+        kl.n = c.n; kl.mstride = a_mstride();
         kl.n_radix = (int)radix[0].size();
         for (int i = 0; i < kl.n_radix; ++i) kl.radix[i] = radix[0][i];
         const int ncols = ny * nz;
-        be->mark(BFSM_K_GAIN_LINE, 3.0 * c.n * (double)G * sizeof(cx<T>));
-        be->template launch_gen<GK::Line3, T>((ncols + GEN_C - 1) / GEN_C, c.n, GEN_THREADS, ((size_t)3 * nx * GEN_LS + nx) * sizeof(cx<T>), kl);
+        be->mark(BFSM_K_GAIN_LINE, 3.0 * c.n * nb * (double)G * sizeof(cx<T>));
+        be->template launch_gen<GK::Line3, T>((ncols + GEN_C - 1) / GEN_C, c.n * nb, GEN_THREADS, ((size_t)3 * nx * GEN_LS + nx) * sizeof(cx<T>), kl);
     }
     // groups of directions per x-plane in the plane-accumulate kernel: about a thousand workgroups per launch
     int groups_for(int n) const {
@@ -943,12 +975,17 @@ struct GenericPipeline {
         const int per = (n + g - 1) / g;
         return per > 0 ? (n + per - 1) / per : 1;
     }
-    void gain_chunk_fused(const Chunk& c, bool first) {
+    // elements between the scratch of two batch members
+    size_t a_mstride() const { return (size_t)2 * chunk * G; }
+    // batches of distributions go through the fused sequence together (every launch covers all members); the other
+    // sequences take them one after the other
+    bool batch_together() const { return fused_ok(); }
+    void gain_chunk_fused(const Chunk& c, bool first, int nb = 1) {
         const double Gc = (double)G * sizeof(cx<T>);
         // A1', A2' = IFFT_yz(alpha f_hat / G), IFFT_yz(conj(alpha) f_hat / G), straight from f_hat (x stays spectral)
-        be->mark(BFSM_K_GAIN_INV, 2.0 * c.n * Gc);
-        plane(fhat, nullptr, a, 2 * c.n, +1, GEN_PHASE, 0, G, c.dir0);
-        line3(c);
+        be->mark(BFSM_K_GAIN_INV, 2.0 * c.n * nb * Gc);
+        plane(fhat, nullptr, a, 2 * c.n * nb, +1, GEN_PHASE, 0, G, c.dir0, 2 * c.n, G, a_mstride());
+        line3(c, nb);
         GenPlaneAccParams<T> kp{};
         const int groups = groups_for(c.n);
         kp.p = a; kp.p_bstride = 2 * G; kp.slab = slab; kp.dirw = dirw; kp.rdir = rdir; kp.beta1 = beta1;
@@ -957,30 +994,31 @@ struct GenericPipeline {
         kp.n_radix = (int)radix[2].size(); kp.n_radix_b = (int)radix[1].size();
         for (int i = 0; i < kp.n_radix; ++i) kp.radix[i] = radix[2][i];
         for (int i = 0; i < kp.n_radix_b; ++i) kp.radix_b[i] = radix[1][i];
-        be->mark(BFSM_K_GAIN_FWD, (1.0 * c.n + groups) * Gc);
-        be->template launch_gen<GK::PlaneAcc, T>(nx, groups, GEN_THREADS, ((size_t)3 * ny * (nz + 1) + ny + nz) * sizeof(cx<T>), kp);
+        kp.groups = groups; kp.p_mstride = a_mstride();
+        be->mark(BFSM_K_GAIN_FWD, (1.0 * c.n + groups) * nb * Gc);
+        be->template launch_gen<GK::PlaneAcc, T>(nx, groups * nb, GEN_THREADS, ((size_t)3 * ny * (nz + 1) + ny + nz) * sizeof(cx<T>), kp);
         // Q_hat (+)= the groups' slabs, fixed order
-        GenAccParams<T> ka{slab, G, qhat, nullptr, nullptr, nullptr, 0, groups, n2stride, first ? 1 : 0, nx, ny, nz};
-        be->mark(BFSM_K_REDUCE, (groups + (first ? 1.0 : 2.0)) * Gc);
-        be->template launch_gen<GK::Acc, T>((int)((G + GEN_THREADS - 1) / GEN_THREADS), 1, GEN_THREADS, 0, ka);
+        GenAccParams<T> ka{slab, G, qhat, nullptr, nullptr, nullptr, 0, groups, n2stride, first ? 1 : 0, nx, ny, nz, (size_t)groups * G, G};
+        be->mark(BFSM_K_REDUCE, (groups + (first ? 1.0 : 2.0)) * nb * Gc);
+        be->template launch_gen<GK::Acc, T>((int)((G + GEN_THREADS - 1) / GEN_THREADS), nb, GEN_THREADS, 0, ka);
     }
 
     // f_hat = FFT(f), then the gain term of this shard into qhat   (CUDABoltzmannOperator.cu:131-191)
+    // nb > 1 (members at f_dev + m G, their f_hat / Q_hat at fhat / qhat + m G) only where batch_together()
     void gain_partial(const double* f_dev, int nb = 1, bool = true) {
-        (void)nb;
         const double Gc = (double)G * sizeof(cx<T>);
         const bool pl = plane_ok();
-        be->mark(BFSM_K_FFT_F, 1.5 * Gc);
-        if (pl) plane(f_dev, nullptr, fhat, 1, -1, GEN_REAL, 0, 0);
+        be->mark(BFSM_K_FFT_F, 1.5 * nb * Gc);
+        if (pl) plane(f_dev, nullptr, fhat, nb, -1, GEN_REAL, G, G);
         else {
-            pass(f_dev, nullptr, fhat, 1, 2, -1, GEN_REAL, 0, 0);
-            be->mark(BFSM_K_FFT_F, 2.0 * Gc); pass(fhat, nullptr, fhat, 1, 1, -1, GEN_PLAIN, 0, 0);
+            pass(f_dev, nullptr, fhat, nb, 2, -1, GEN_REAL, G, G);
+            be->mark(BFSM_K_FFT_F, 2.0 * nb * Gc); pass(fhat, nullptr, fhat, nb, 1, -1, GEN_PLAIN, G, G);
         }
-        be->mark(BFSM_K_FFT_F, 2.0 * Gc); pass(fhat, nullptr, fhat, 1, 0, -1, GEN_PLAIN, 0, 0);
+        be->mark(BFSM_K_FFT_F, 2.0 * nb * Gc); pass(fhat, nullptr, fhat, nb, 0, -1, GEN_PLAIN, G, G);
         bool first = true;
         const bool fused = fused_ok(), l3 = line3_ok((size_t)150 * 1024);
         for (const Chunk& c : plan.chunks) {
-            if (fused) { gain_chunk_fused(c, first); first = false; continue; }
+            if (fused) { gain_chunk_fused(c, first, nb); first = false; continue; }
             const int nb2 = 2 * c.n;
             if (l3) {
                 // the (y,z) passes of the inverse transforms first (phase factors on the load side, straight from f_hat), then
@@ -1029,36 +1067,36 @@ struct GenericPipeline {
             first = false;
         }
         if (first) {   // empty shard: qhat = 0
-            GenAccParams<T> ka{a, 2 * G, qhat, dirw, rdir, beta1, 0, 0, n2stride, 1, nx, ny, nz};
+            GenAccParams<T> ka{a, 2 * G, qhat, dirw, rdir, beta1, 0, 0, n2stride, 1, nx, ny, nz, 0, G};
             be->mark(-1, 0);
-            be->template launch_gen<GK::Acc, T>((int)((G + GEN_THREADS - 1) / GEN_THREADS), 1, GEN_THREADS, 0, ka);
+            be->template launch_gen<GK::Acc, T>((int)((G + GEN_THREADS - 1) / GEN_THREADS), nb, GEN_THREADS, 0, ka);
         }
     }
 
     // loss term + final inverse transforms + combine   (CUDABoltzmannOperator.cu:193-216)
     void finish(double* Q_dev, const double* f_dev, bool with_loss = true, int nb = 1, bool = false) {
-        (void)nb;
         const double Gc = (double)G * sizeof(cx<T>);
-        cx<T>* tg = tail;
-        cx<T>* tl = tail + G;
-        be->mark(BFSM_K_TAIL, (with_loss ? 7.0 : 3.5) * Gc);
+        cx<T>* tg = tail;                                   // [max_batch][G] gain, then [max_batch][G] loss
+        cx<T>* tl = tail + (size_t)max_batch * G;
+        be->mark(BFSM_K_TAIL, (with_loss ? 7.0 : 3.5) * nb * Gc);
         const bool pl = plane_ok();
         auto yz = [&](cx<T>* t) {
-            if (pl) { be->mark(BFSM_K_TAIL, 0); plane(t, nullptr, t, 1, +1, GEN_PLAIN, 0, 0); }
+            if (pl) { be->mark(BFSM_K_TAIL, 0); plane(t, nullptr, t, nb, +1, GEN_PLAIN, G, G); }
             else {
-                be->mark(BFSM_K_TAIL, 0); pass(t, nullptr, t, 1, 1, +1, GEN_PLAIN, 0, 0);
-                be->mark(BFSM_K_TAIL, 0); pass(t, nullptr, t, 1, 2, +1, GEN_PLAIN, 0, 0);
+                be->mark(BFSM_K_TAIL, 0); pass(t, nullptr, t, nb, 1, +1, GEN_PLAIN, G, G);
+                be->mark(BFSM_K_TAIL, 0); pass(t, nullptr, t, nb, 2, +1, GEN_PLAIN, G, G);
             }
         };
-        pass(qhat, nullptr, tg, 1, 0, +1, GEN_PLAIN, 0, 0);
+        pass(qhat, nullptr, tg, nb, 0, +1, GEN_PLAIN, G, G);
         yz(tg);
         if (with_loss) {
-            be->mark(BFSM_K_TAIL, 0); pass(fhat, nullptr, tl, 1, 0, +1, GEN_BETA2, 0, 0);
+            be->mark(BFSM_K_TAIL, 0); pass(fhat, nullptr, tl, nb, 0, +1, GEN_BETA2, G, G);
             yz(tl);
         }
-        GenCombineParams<T> kc{tg, tl, f_dev, Q_dev, G, with_loss ? 1 : 0};
+        const size_t tot = (size_t)nb * G;                  // members are contiguous in every array involved
+        GenCombineParams<T> kc{tg, tl, f_dev, Q_dev, tot, with_loss ? 1 : 0};
         be->mark(BFSM_K_TAIL, 0);
-        be->template launch_gen<GK::Combine, T>((int)((G + GEN_THREADS - 1) / GEN_THREADS), 1, GEN_THREADS, 0, kc);
+        be->template launch_gen<GK::Combine, T>((int)((tot + GEN_THREADS - 1) / GEN_THREADS), 1, GEN_THREADS, 0, kc);
     }
 
     // In-place batched 3-D transform on user data (bfsm_fft3d); natural layouts on both sides

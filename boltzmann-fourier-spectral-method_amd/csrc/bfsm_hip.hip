@@ -742,9 +742,13 @@ int bfsm_collide_batch_partial_async(bfsm_handle h, double* Q_dev, const double*
         if (n_batch < 1 || n_batch > cap)
             return fail(h, BFSM_ERR_INVALID, "n_batch must be in [1, max_batch of the descriptor]");
         h->be.begin_eval();
-        if (h->g64 || h->g32) {      // the size-generic path evaluates the members one after the other
-            for (int i = 0; i < n_batch; ++i)
-                h->with([&](auto& p) { p.gain_partial(f_dev + (size_t)i * h->G); p.finish(Q_dev + (size_t)i * h->G, f_dev + (size_t)i * h->G, with_loss != 0); });
+        if (h->g64 || h->g32) {      // size-generic path: all members through every launch of the fused sequence, else one by one
+            bool together = false;
+            h->with([&](auto& p) { together = p.batch_together(); });
+            if (together) h->with([&](auto& p) { p.gain_partial(f_dev, n_batch); p.finish(Q_dev, f_dev, with_loss != 0, n_batch); });
+            else
+                for (int i = 0; i < n_batch; ++i)
+                    h->with([&](auto& p) { p.gain_partial(f_dev + (size_t)i * h->G); p.finish(Q_dev + (size_t)i * h->G, f_dev + (size_t)i * h->G, with_loss != 0); });
         } else {
             h->with([&](auto& p) {
                 // a batch of one on a single-evaluation N = 16 handle takes the same whole-direction kernels as bfsm_collide

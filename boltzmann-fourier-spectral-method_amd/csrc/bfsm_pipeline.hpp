@@ -429,6 +429,7 @@ struct Pipeline {
     // N (x 2) workgroups, each walking all slabs: it pays for few slabs (a 1/8 shard of cfg3: 0.445 -> 0.439 ms per
     // evaluation) and loses against the wide reduce kernel for many (cfg2, 64 slabs: 4.0 k -> 2.8 k evaluations/s).
     bool fuse_reduce() const { return slab_count <= 8; }
+    bool batch_together() const { return true; }          // batches of distributions share every launch
 
     // do_reduce = false leaves the slabs un-summed (qhat is not written): for callers that continue with
     // finish(..., from_slabs = true) in the same call and never expose qhat.

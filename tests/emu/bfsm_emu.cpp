@@ -291,6 +291,14 @@ int collide_gen_t(const bfsm_desc* d, const double* f, double* Q, double* qhat_o
     int rc = p.init(*d, &be, err);
     if (rc) return rc;
     if (nb < 1 || nb > p.max_batch) return BFSM_ERR_INVALID;
+    if (p.batch_together()) {                 // as bfsm_collide_batch_partial_async: all members through every launch
+        p.gain_partial(f, nb);
+        if (qhat_out)
+            for (size_t k = 0; k < p.G * (size_t)nb; ++k) { qhat_out[2 * k] = (double)p.qhat[k].x; qhat_out[2 * k + 1] = (double)p.qhat[k].y; }
+        if (Q) p.finish(Q, f, with_loss, nb);
+        p.destroy();
+        return be.failed ? 99 : 0;
+    }
     for (int i = 0; i < nb; ++i) {
         p.gain_partial(f + (size_t)i * p.G);
         if (qhat_out)

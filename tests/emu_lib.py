@@ -134,9 +134,10 @@ class EmuOperator:
 
 
 def collide_batch(fs, gl, sph, gamma, b_gamma, L, precision=64, max_chunk=0, flags=0):
-    """fs: [n_batch][nv][nv][nv]; one emulated bfsm_collide_batch call.  Returns Q with the same shape."""
+    """fs: [n_batch][nvx][nvy][nvz]; one emulated bfsm_collide_batch call.  Returns Q with the same shape."""
     fs = np.ascontiguousarray(fs, dtype=np.float64)
-    nb, nv = fs.shape[0], fs.shape[1]
+    nb = fs.shape[0]
+    nv = fs.shape[1] if fs.shape[1] == fs.shape[2] == fs.shape[3] else fs.shape[1:]
     d, keep = make_desc(nv, gl, sph, gamma, b_gamma, L, precision, (0, 0), max_chunk, flags, max_batch=nb)
     L_ = lib()
     dp = ctypes.POINTER(ctypes.c_double)

@@ -378,6 +378,23 @@ def test_size_generic_path_matches_oracle(oracle, shape, n_gl, n_sph, prec, tol,
         assert np.abs(Q - Qo).max() <= tol * np.abs(Qo).max()
 
 
+@pytest.mark.parametrize("shape,max_chunk", [((16, 8, 6), 0), ((16, 8, 6), 7), ((8, 14, 6), 0)])
+def test_size_generic_batch_of_distributions(oracle, shape, max_chunk):
+    """A batch on the size-generic path: the fused sequence takes all members through every launch (own f_hat, scratch,
+    slabs and Q_hat per member), the other sequences one member after the other -- either way bitwise the single
+    evaluations, and the oracle's result."""
+    rng = np.random.default_rng(11)
+    fs = rng.random((3,) + shape) + 0.1
+    gl = oracle.gauss_legendre(3, 0.0, R)
+    sph = oracle.spherical_design(6)
+    Qb = E.collide_batch(fs, gl, sph, 0.5, 0.3, 11.0, max_chunk=max_chunk)
+    for i in range(3):
+        Qi, _ = E.collide(fs[i], gl, sph, 0.5, 0.3, 11.0, 64, max_chunk=max_chunk)
+        assert np.array_equal(Qb[i], Qi)
+        Qo = oracle.collide(fs[i], gl, sph, 0.5, 0.3, 11.0)
+        assert np.abs(Qb[i] - Qo).max() <= 1e-12 * np.abs(Qo).max()
+
+
 @pytest.mark.parametrize("n_gl,n_sph,flags,rng,prec,tol", [
     (3, 12, 0, (0, 0), 64, 1e-12),          # faithful: one forward transform per direction
     (8, 32, 0, (0, 0), 64, 1e-12),          # config 1: 256 directions, one per workgroup
