@@ -746,14 +746,16 @@ template <int N, typename T> constexpr bool keep_plane() { return !split_tile<N,
 // workgroup per CU: nothing else overlaps its exchanges) and at N = 64 in double precision (two workgroups per CU, and
 // still 7 % faster: 12 barriers per direction instead of 14, every burst of LDS stores under the other tile's
 // butterflies; 114 VGPRs.  In single precision at N = 64, where four and more workgroups share a CU, it is 7 % slower).  BFSM_NO_PIPELINED_PAIR restores the one-tile-after-the-other form everywhere,
-// BFSM_NO_PIPELINED_PAIR_64 at N = 64 only (A/B measurements).
+// BFSM_NO_PIPELINED_PAIR_64 at N = 64 only (A/B measurements).  N = 96 (one 384-thread workgroup per CU; the f_hat plane is
+// re-read per direction in double precision, 255 VGPRs, no scratch): KA 4.07 -> 3.22 ms in double, 2.18 -> 2.06 ms in single
+// precision at 384 directions; at N = 80 it is 4 % slower (profiles/r04_other_sizes.txt).
 template <int N, typename T> constexpr bool pipelined_pair() {
 #ifdef BFSM_NO_PIPELINED_PAIR
     return false;
 #elif defined(BFSM_NO_PIPELINED_PAIR_64)
     return N >= 128 && !split_tile<N, T>();
 #else
-    return (N >= 128 && !split_tile<N, T>()) || (N == 64 && sizeof(T) == 8);
+    return (N >= 128 && !split_tile<N, T>()) || (N == 64 && sizeof(T) == 8) || N == 96;
 #endif
 }
 
@@ -1049,8 +1051,10 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
 #pragma unroll
             for (int m = 0; m < E; ++m) {
                 const cx<T> ph = cmul(c0, ctx.ldc(prm.phz + b * N + u + TT * m));
-                va[m] = cmul(fh[m], ph);        // alpha1 f_hat / G
-                if constexpr (SHARE) vb[m] = cmulc(fh[m], ph);       // conj(alpha1) f_hat / G
+                cx<T> fm;
+                if constexpr (KEEP) fm = fh[m]; else fm = src[(u + TT * m) * N + p];   // plane not held: re-read (L2)
+                va[m] = cmul(fm, ph);           // alpha1 f_hat / G
+                if constexpr (SHARE) vb[m] = cmulc(fm, ph);          // conj(alpha1) f_hat / G
             }
             SmallDft<E, +1, T>::run(va);
             BFSM_TSYNC(0);                         // the previous direction's last exchange has been read
@@ -1059,7 +1063,11 @@ BFSM_HD void body_gain_inv(const GainInvParams<T>& prm, Ctx& ctx) {
             if constexpr (!SHARE) {
                 const cx<T> c0s = ctx.opaque_cx(c0);
 #pragma unroll
-                for (int m = 0; m < E; ++m) vb[m] = cmulc(fh[m], cmul(c0s, ctx.ldc(prm.phz + b * N + u + TT * m)));
+                for (int m = 0; m < E; ++m) {
+                    cx<T> fm;
+                    if constexpr (KEEP) fm = fh[m]; else fm = src[(u + TT * m) * N + p];
+                    vb[m] = cmulc(fm, cmul(c0s, ctx.ldc(prm.phz + b * N + u + TT * m)));
+                }
             }
             SmallDft<E, +1, T>::run(vb);
             BFSM_TSYNC(1); xr_line(wa); BFSM_TSYNC(2);
