@@ -748,14 +748,15 @@ template <int N, typename T> constexpr bool keep_plane() { return !split_tile<N,
 // butterflies; 114 VGPRs.  In single precision at N = 64, where four and more workgroups share a CU, it is 7 % slower).  BFSM_NO_PIPELINED_PAIR restores the one-tile-after-the-other form everywhere,
 // BFSM_NO_PIPELINED_PAIR_64 at N = 64 only (A/B measurements).  N = 96 (one 384-thread workgroup per CU; the f_hat plane is
 // re-read per direction in double precision, 255 VGPRs, no scratch): KA 4.07 -> 3.22 ms in double, 2.18 -> 2.06 ms in single
-// precision at 384 directions; at N = 80 it is 4 % slower (profiles/r04_other_sizes.txt).
+// precision at 384 directions; at N = 80 it is 4 % slower.  N = 24: KA 0.072 -> 0.048 ms (fp64), 0.039 -> 0.034 (fp32); N = 40:
+// -3 %; N = 48: -6 % in single, +1 % in double precision (profiles/r04_other_sizes.txt).
 template <int N, typename T> constexpr bool pipelined_pair() {
 #ifdef BFSM_NO_PIPELINED_PAIR
     return false;
 #elif defined(BFSM_NO_PIPELINED_PAIR_64)
     return N >= 128 && !split_tile<N, T>();
 #else
-    return (N >= 128 && !split_tile<N, T>()) || (N == 64 && sizeof(T) == 8) || N == 96;
+    return (N >= 128 && !split_tile<N, T>()) || (N == 64 && sizeof(T) == 8) || N == 96 || N == 24 || N == 40 || (N == 48 && sizeof(T) == 4);
 #endif
 }
 
