@@ -571,6 +571,76 @@ BFSM_HD void body_gen_line3(const GenLineParams<T>& prm, Ctx& ctx) {
         for (int pt = p0; pt < n; pt += STEP) A1[(size_t)pt * ps] = src[pt * GEN_LS + cl];
 }
 
+// KA of the cubes in size-generic form: the phase multiply (compute_alpha_times_f_hat, Kernels.cu:21-59) and the (y,z) part
+// of BOTH inverse transforms of one direction's x-plane, straight from f_hat.  grid = (nx planes, members x directions).
+// f_hat and the phase factor of every element the thread owns are formed once and kept in registers; sign 0 takes f_hat ph,
+// sign 1 f_hat conj(ph) (alpha2 = conj(alpha1), FFTWBoltzmannOperator.cpp:219-224).  out: member m at + m out_mstride,
+// direction d's two planes at batch slots 2d, 2d + 1.
+template <typename T>
+constexpr int gen_plane_maxe() { return (int)((size_t)40 * 1024 / (2 * sizeof(cx<T>)) + GEN_THREADS - 1) / GEN_THREADS; }
+template <typename T, class Ctx>
+BFSM_HD void body_gen_plane_pair(const GenFftParams<T>& prm, Ctx& ctx) {
+    constexpr int MAXE = gen_plane_maxe<T>();
+    const int nx = prm.nx, ny = prm.ny, nz = prm.nz;
+    const int ix = ctx.bx();
+    const int mem = ctx.by() / prm.mper, d = ctx.by() - mem * prm.mper;
+    const int LSZ = nz + 1;
+    cx<T>* buf0 = ctx.template lds<cx<T>>();
+    cx<T>* buf1 = buf0 + (size_t)ny * LSZ;
+    cx<T>* twa = buf1 + (size_t)ny * LSZ;
+    cx<T>* twb = twa + ny;
+    gen_stage_tw<T>(twa, prm.tw, ny, ctx);
+    gen_stage_tw<T>(twb, prm.tw_b, nz, ctx);
+    const int plane = ny * nz;
+    const size_t G = (size_t)nx * plane, base = (size_t)ix * plane;
+    const int dy = GEN_THREADS / nz, dz = GEN_THREADS - dy * nz;
+    const int iy0 = ctx.tid() / nz, iz0 = ctx.tid() - iy0 * nz;
+    const cx<T>* fh = static_cast<const cx<T>*>(prm.in) + (size_t)mem * prm.in_mstride + base;
+    const size_t gd = (size_t)(prm.dir0 + d);
+    const cx<T> px = prm.phx[gd * nx + ix];
+    cx<T> fr[MAXE], ph[MAXE];
+    {
+        int iy = iy0, iz = iz0;
+#pragma unroll
+        for (int k = 0; k < MAXE; ++k) {
+            const int e = ctx.tid() + k * GEN_THREADS;
+            fr[k] = {(T)0, (T)0};
+            ph[k] = {(T)0, (T)0};
+            if (e < plane) {
+                fr[k] = fh[e];
+                ph[k] = cmul(px, cmul(prm.phy[gd * ny + iy], prm.phz[gd * nz + iz]));
+            }
+            iy += dy; iz += dz;
+            if (iz >= nz) { iz -= nz; ++iy; }
+        }
+    }
+    for (int sgn2 = 0; sgn2 < 2; ++sgn2) {
+        int iy = iy0, iz = iz0;
+#pragma unroll
+        for (int k = 0; k < MAXE; ++k) {
+            if (ctx.tid() + k * GEN_THREADS < plane) buf0[iy * LSZ + iz] = sgn2 ? cmulc(fr[k], ph[k]) : cmul(fr[k], ph[k]);
+            iy += dy; iz += dz;
+            if (iz >= nz) { iz -= nz; ++iy; }
+        }
+        ctx.sync();
+        cx<T>* src = buf0;
+        cx<T>* dst = buf1;
+        gen_plane_axis<T>(src, dst, twa, prm.radix, prm.n_radix, ny, +1, nz, LSZ, 1, ctx);
+        gen_plane_axis<T>(src, dst, twb, prm.radix_b, prm.n_radix_b, nz, +1, ny, 1, LSZ, ctx);
+        // a thread stores its own elements of src; what it then overwrites in buf0 for the second sign it has read itself (src =
+        // buf0), or nobody reads any more (src = buf1: the last pass' reads of buf0 ended before its barrier)
+        cx<T>* out = prm.out + (size_t)mem * prm.out_mstride + (size_t)(2 * d + sgn2) * G + base;
+        iy = iy0; iz = iz0;
+#pragma unroll
+        for (int k = 0; k < MAXE; ++k) {
+            const int e = ctx.tid() + k * GEN_THREADS;
+            if (e < plane) out[e] = src[iy * LSZ + iz];
+            iy += dy; iz += dz;
+            if (iz >= nz) { iz -= nz; ++iy; }
+        }
+    }
+}
+
 // (y,z) forward transform + accumulate, KC of the cubes in size-generic form.  grid = (nx planes, groups of directions).
 // The workgroup streams the P' planes of its directions once, summing dirw_d P'_d in LDS while the radial node stays the
 // same (the transform is linear: one transform per run of equal radial nodes, like kc_sum_before_transform on the
@@ -704,7 +774,7 @@ BFSM_HD void body_gen_combine(const GenCombineParams<T>& prm, Ctx& ctx) {
     prm.Q[idx] = q;
 }
 
-enum class GK { Fft, Acc, Combine, FftBig, Plane, Line3, PlaneAcc };   // FftBig: Fft + the radix-7 / 11 / 13 passes; Plane: y and z
+enum class GK { Fft, Acc, Combine, FftBig, Plane, Line3, PlaneAcc, PlanePair };   // FftBig: Fft + the radix-7 / 11 / 13 passes; Plane: y and z
                                                                       // pass fused; Line3 / PlaneAcc: the fused sequence
 
 inline bool gen_factor(int n, std::vector<int>& radix) {
@@ -991,7 +1061,26 @@ struct GenericPipeline {
         const double Gc = (double)G * sizeof(cx<T>);
         // A1', A2' = IFFT_yz(alpha f_hat / G), IFFT_yz(conj(alpha) f_hat / G), straight from f_hat (x stays spectral)
         be->mark(BFSM_K_GAIN_INV, 2.0 * c.n * nb * Gc);
-        plane(fhat, nullptr, a, 2 * c.n * nb, +1, GEN_PHASE, 0, G, c.dir0, 2 * c.n, G, a_mstride());
+#ifdef BFSM_GEN_NO_PLANE_PAIR     // A/B builds (tools only): one workgroup per sign
+        constexpr bool PAIR = false;
+#else
+        // both signs in one workgroup (f_hat and the phase factors formed once): double precision 0.195 -> 0.156 ms at 32 x 64 x 16;
+        // single precision keeps one workgroup per sign (49 VGPRs and 18 KB of LDS: twice the residency; the pair form measured
+        // 0.117 -> 0.133 ms there) -- profiles/r04_generic_fused_ab.txt
+        constexpr bool PAIR = sizeof(T) == 8;
+#endif
+        if (!PAIR) plane(fhat, nullptr, a, 2 * c.n * nb, +1, GEN_PHASE, 0, G, c.dir0, 2 * c.n, G, a_mstride());
+        else {
+            GenFftParams<T> ki{};
+            ki.in = fhat; ki.out = a; ki.nx = nx; ki.ny = ny; ki.nz = nz; ki.axis = 1; ki.sign = +1; ki.C = GEN_C; ki.mode = GEN_PHASE;
+            ki.tw = tw[1]; ki.tw_b = tw[2];
+            ki.n_radix = (int)radix[1].size(); ki.n_radix_b = (int)radix[2].size();
+            for (int i = 0; i < ki.n_radix; ++i) ki.radix[i] = radix[1][i];
+            for (int i = 0; i < ki.n_radix_b; ++i) ki.radix_b[i] = radix[2][i];
+            ki.phx = phx; ki.phy = phy; ki.phz = phz; ki.dir0 = c.dir0;
+            ki.mper = c.n; ki.in_mstride = G; ki.out_mstride = a_mstride();
+            be->template launch_gen<GK::PlanePair, T>(nx, c.n * nb, GEN_THREADS, ((size_t)2 * ny * (nz + 1) + ny + nz) * sizeof(cx<T>), ki);
+        }
         line3(c, nb);
         GenPlaneAccParams<T> kp{};
         const int groups = groups_for(c.n);

@@ -391,6 +391,7 @@ __global__ void __launch_bounds__(GEN_THREADS) bfsm_gen_kernel(const P prm) {
     else if constexpr (kind == GK::Combine) body_gen_combine<T>(prm, ctx);
     else if constexpr (kind == GK::Line3) body_gen_line3<T>(prm, ctx);
     else if constexpr (kind == GK::PlaneAcc) body_gen_plane_acc<T>(prm, ctx);
+    else if constexpr (kind == GK::PlanePair) body_gen_plane_pair<T>(prm, ctx);
 }
 
 // N = 16 whole-direction kernels: 256 threads, two padded cubes of LDS

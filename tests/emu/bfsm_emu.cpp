@@ -252,6 +252,7 @@ struct EmuBackend {
         else if constexpr (kind == bfsm::GK::Combine) bfsm::body_gen_combine<T>(prm, ctx);
         else if constexpr (kind == bfsm::GK::Line3) bfsm::body_gen_line3<T>(prm, ctx);
         else if constexpr (kind == bfsm::GK::PlaneAcc) bfsm::body_gen_plane_acc<T>(prm, ctx);
+        else if constexpr (kind == bfsm::GK::PlanePair) bfsm::body_gen_plane_pair<T>(prm, ctx);
     }
 
     template <bfsm::GK kind, typename T, class P>
