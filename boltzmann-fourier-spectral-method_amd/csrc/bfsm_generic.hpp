@@ -32,7 +32,9 @@ constexpr int GEN_MAX_N = 256;
 constexpr int GEN_THREADS = 256;
 
 // load-side fusions of a pass
-enum : int { GEN_PLAIN = 0, GEN_PHASE = 1, GEN_PRODUCT = 2, GEN_REAL = 3, GEN_BETA2 = 4 };
+enum : int { GEN_PLAIN = 0, GEN_PHASE = 1, GEN_PRODUCT = 2, GEN_REAL = 3, GEN_BETA2 = 4, GEN_TAIL2 = 5 };
+// GEN_TAIL2 (x pass of the tail): slot 0 of a member transforms in (Q_hat) as it is, slot 1 transforms beta2 * in2 (f_hat) -- the
+// gain and the loss term in one launch
 
 template <typename T>
 struct GenFftParams {
@@ -305,6 +307,8 @@ BFSM_HD void body_gen_fft(const GenFftParams<T>& prm, Ctx& ctx) {
         const cx<T> px = prm.phx[d * nx + i0x], py = prm.phy[d * ny + i0y], pz = prm.phz[d * nz + i0z];
         ph_line = axis == 0 ? cmul(py, pz) : (axis == 1 ? cmul(px, pz) : cmul(px, py));
     }
+    const bool loss_slot = prm.mode == GEN_TAIL2 && (b & 1);
+    const cx<T>* inc = loss_slot ? prm.in2 : static_cast<const cx<T>*>(prm.in);
     // the global loads are issued four points at a time before any of them is consumed: the trip count is a run-time
     // value, and a rolled loop would pay one full memory latency per point
     constexpr int STEP = GEN_THREADS / GEN_C, CH = 4;
@@ -318,7 +322,7 @@ BFSM_HD void body_gen_fft(const GenFftParams<T>& prm, Ctx& ctx) {
             if (live && pt < n) {
                 const size_t idx = base + (size_t)pt * ps;
                 if (prm.mode == GEN_REAL) vin[i].x = (T) static_cast<const double*>(prm.in)[in_off + idx];
-                else vin[i] = static_cast<const cx<T>*>(prm.in)[in_off + idx];
+                else vin[i] = inc[in_off + idx];
                 if (prm.mode == GEN_PRODUCT) vin2[i] = prm.in2[in_off + idx];
             }
         }
@@ -330,7 +334,7 @@ BFSM_HD void body_gen_fft(const GenFftParams<T>& prm, Ctx& ctx) {
                 if (live) {
                     if (prm.mode == GEN_PRODUCT) {
                         v = cmul(v, vin2[i]);
-                    } else if (prm.mode == GEN_PHASE || prm.mode == GEN_BETA2) {
+                    } else if (prm.mode == GEN_PHASE || prm.mode == GEN_BETA2 || loss_slot) {
                         const int ix = axis == 0 ? pt : i0x, iy = axis == 1 ? pt : i0y, iz = axis == 2 ? pt : i0z;
                         if (prm.mode == GEN_PHASE) {
                             const size_t d = (size_t)(prm.dir0 + (b >> 1));
@@ -747,7 +751,15 @@ BFSM_HD void body_gen_acc(const GenAccParams<T>& prm, Ctx& ctx) {
     cx<T>* qh = prm.qhat + (size_t)ctx.by() * prm.q_mstride;
     cx<T> q = prm.first ? cx<T>{(T)0, (T)0} : qh[idx];
     if (!prm.dirw) {                          // no weights: the members are slabs of the fused sequence, already weighted
-        for (int d = 0; d < prm.n; ++d) {
+        int d = 0;
+        for (; d + 8 <= prm.n; d += 8) {          // eight loads in flight, added in the same fixed order
+            cx<T> t[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t[i] = pp[(size_t)(d + i) * prm.p_bstride + idx];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { q.x += t[i].x; q.y += t[i].y; }
+        }
+        for (; d < prm.n; ++d) {
             const cx<T> t = pp[(size_t)d * prm.p_bstride + idx];
             q.x += t.x;
             q.y += t.y;
@@ -962,8 +974,9 @@ struct GenericPipeline {
     // one axis pass over `batch` arrays; member b of in / out sits at + b * in_bstride / + b * out_bstride.  A pass may
     // run in place: every workgroup reads its whole block of lines into LDS before it stores the same block.
     void pass(const void* in, const cx<T>* in2, cx<T>* out, int batch, int axis, int sign, int mode, size_t in_bstride,
-              size_t out_bstride, long long dir0 = 0) {
+              size_t out_bstride, long long dir0 = 0, int mper = 0, size_t in_mstride = 0, size_t out_mstride = 0) {
         GenFftParams<T> p{};
+        p.mper = mper; p.in_mstride = in_mstride; p.out_mstride = out_mstride;
         p.in = in; p.in2 = in2; p.out = out; p.tw = tw[axis];
         p.nx = nx; p.ny = ny; p.nz = nz; p.axis = axis; p.sign = sign;
         const int n = axis_len(axis);
@@ -1183,11 +1196,18 @@ struct GenericPipeline {
                 be->mark(BFSM_K_TAIL, 0); pass(t, nullptr, t, nb, 2, +1, GEN_PLAIN, G, G);
             }
         };
-        pass(qhat, nullptr, tg, nb, 0, +1, GEN_PLAIN, G, G);
-        yz(tg);
         if (with_loss) {
-            be->mark(BFSM_K_TAIL, 0); pass(fhat, nullptr, tl, nb, 0, +1, GEN_BETA2, G, G);
-            yz(tl);
+            // gain and loss term through the same launches: slot s of member m at tail + (s max_batch + m) G
+            const size_t half = (size_t)max_batch * G;
+            pass(qhat, fhat, tail, 2 * nb, 0, +1, GEN_TAIL2, 0, half, 0, 2, G, G);
+            if (pl) { be->mark(BFSM_K_TAIL, 0); plane(tail, nullptr, tail, 2 * nb, +1, GEN_PLAIN, G, G, 0, nb, half, half); }
+            else {
+                be->mark(BFSM_K_TAIL, 0); pass(tail, nullptr, tail, 2 * nb, 1, +1, GEN_PLAIN, G, G, 0, nb, half, half);
+                be->mark(BFSM_K_TAIL, 0); pass(tail, nullptr, tail, 2 * nb, 2, +1, GEN_PLAIN, G, G, 0, nb, half, half);
+            }
+        } else {
+            pass(qhat, nullptr, tg, nb, 0, +1, GEN_PLAIN, G, G);
+            yz(tg);
         }
         const size_t tot = (size_t)nb * G;                  // members are contiguous in every array involved
         GenCombineParams<T> kc{tg, tl, f_dev, Q_dev, tot, with_loss ? 1 : 0};
