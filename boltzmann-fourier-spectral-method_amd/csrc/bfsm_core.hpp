@@ -2019,7 +2019,23 @@ BFSM_HD void body_small_reduce(const SmallReduceParams<T>& prm, Ctx& ctx) {
     double* lds = ctx.template lds<double>();
     const int per = (prm.n_part + 15) / 16;
     double q = 0;
-    for (int w = g * per; w < (g + 1) * per && w < prm.n_part; ++w) q += (double)prm.part[(size_t)w * 4096 + idx];
+    int w = g * per, w1 = (g + 1) * per;
+    if (w1 > prm.n_part) w1 = prm.n_part;
+    for (; w + 16 <= w1; w += 16) {          // sixteen loads in flight (a group's whole share at config 1), added in the same
+        T t[16];                             // fixed order
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t[i] = prm.part[(size_t)(w + i) * 4096 + idx];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) q += (double)t[i];
+    }
+    for (; w + 4 <= w1; w += 4) {
+        T t[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i] = prm.part[(size_t)(w + i) * 4096 + idx];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q += (double)t[i];
+    }
+    for (; w < w1; ++w) q += (double)prm.part[(size_t)w * 4096 + idx];
     lds[g * 16 + pt] = q;
     ctx.sync();
     if (g == 0) {
