@@ -421,3 +421,16 @@ def test_whole_direction_kernels_n16(oracle, n_gl, n_sph, flags, rng, prec, tol)
         g = E.collide_partial(f, gl, sph, GAMMA, B_GAMMA, L, prec, dir_range=rng, with_loss=False, flags=flags)
         g2 = E.collide_partial(f, gl, sph, GAMMA, B_GAMMA, L, prec, dir_range=rng, with_loss=False, flags=flags | 8)
         assert np.abs(g - g2).max() <= tol * np.abs(ref).max()
+
+
+def test_reciprocal_division_of_the_size_generic_passes_is_exact():
+    """csrc/bfsm_generic.hpp gen_div: floor(w / d) = (int)((float(w) + 0.5f) * (1.0f / d)) for every w < 65536, d <= 256 -- the
+    index arithmetic of the size-generic pass loops.  Checked exhaustively in float32, also with the reciprocal one ulp
+    low and one ulp high (a device reciprocal that is not correctly rounded)."""
+    w = np.arange(65536, dtype=np.int64)
+    wf = w.astype(np.float32) + np.float32(0.5)
+    for d in range(1, 257):
+        inv = np.float32(1.0) / np.float32(d)
+        for r in (inv, np.nextafter(inv, np.float32(0)), np.nextafter(inv, np.float32(2))):
+            got = (wf * r).astype(np.int32)            # float32 product, truncation: what the kernels do
+            assert np.array_equal(got, w // d), d
