@@ -6,10 +6,11 @@
 // per direction); everything else runs here, on mixed-radix (8, 4, 2, 3, 5; 7, 11, 13 table-driven) Stockham passes in LDS
 // with runtime sizes.  Three sequences, chosen per box in GenericPipeline (profiles/r04_generic_fused_ab.txt):
 //   * the (y,z) plane fits the LDS (most boxes up to ~1300 plane points in double precision): the cubic pipeline's three
-//     kernels in size-generic form -- body_gen_plane straight from f_hat with the phase multiply on its load side
-//     (compute_alpha_times_f_hat, BoltzmannCUDAKernels.cu:21-59), body_gen_line3 (x part of both inverse transforms,
+//     kernels in size-generic form -- body_gen_plane_pair / body_gen_plane straight from f_hat with the phase multiply on the
+//     load side (compute_alpha_times_f_hat, BoltzmannCUDAKernels.cu:21-59), body_gen_line3 (x part of both inverse transforms,
 //     hadamard_product Kernels.cu:62-74, x part of the forward transform), body_gen_plane_acc ((y,z) forward transform +
-//     atomic-free accumulate, Kernels.cu:79-123) -- 6 array moves per direction, 2.2-2.6 TB/s algorithmic;
+//     atomic-free accumulate, Kernels.cu:79-123) -- 6 array moves per direction, 2.5-2.9 TB/s algorithmic; batches of
+//     distributions go through these launches together;
 //   * bigger planes: per-axis passes with the x-line kernel in the middle, 14 moves (8 where only the x lines are too long
 //     for the first form);
 //   * x axes with a factor 7, 11 or 13: one pass per axis (or x + a plane pass), 18 / 12 moves.
@@ -218,7 +219,7 @@ constexpr int GEN_LS = GEN_C + 1;
 
 // One Stockham pass of radix R over GEN_C lines of n points held in LDS as [point][line] (row stride GEN_LS).
 // ns = product of the radices already applied; NS_POW2: ns is a power of two (shift / mask instead of division: the
-// plan orders the radices 4, 2 first and 3, 5 last, so only passes behind an odd radix take the general form).
+// plan orders the radices 8, 4, 2 first and 3, 5 last, so only passes behind an odd radix take the general form).
 // The axis' twiddle table copied into LDS next to the line buffers: a pass reads R - 1 table values per butterfly, and a
 // global (cached) load costs a pass most of a microsecond of latency that nothing hides in workgroups this small
 // (round 4: the y/z plane kernel of 32 x 64 x 16 took 10 us per workgroup, half of it waiting for twiddles).
@@ -261,7 +262,7 @@ BFSM_HD void gen_pass(const cx<T>* src, cx<T>* dst, const cx<T>* tw, int n, int 
 }
 
 // Batched 1-D transform along one axis.  grid = (blocks of GEN_C lines, batch).  Workgroup: GEN_THREADS threads, LDS =
-// two buffers of n x (GEN_C + 1) complex.  A "line" is the set of n points along the transformed axis; consecutive
+// two buffers of n x (GEN_C + 1) complex + the axis' n twiddles.  A "line" is the set of n points along the transformed axis; consecutive
 // lines are consecutive in z (axes x, y) or consecutive (x, y) pairs (axis z).
 // BIG: the instantiation that also carries the table-driven radix-7 / 11 / 13 butterflies (13 complex inputs + 13 outputs
 // in registers: 256 VGPRs and a kilobyte of scratch per lane in double precision).  Axes whose factors are 2, 3, 5 only --
@@ -650,6 +651,7 @@ BFSM_HD void body_gen_plane_pair(const GenFftParams<T>& prm, Ctx& ctx) {
 // same (the transform is linear: one transform per run of equal radial nodes, like kc_sum_before_transform on the
 // cubes), transforms the sum, weights it with beta1[r](|l|^2) (atomic_tensor_contraction, Kernels.cu:79-123, without the
 // atomics) and adds it to a spectral accumulator; one slab plane per workgroup leaves at the end.  LDS: three planes.
+// grid.y = members x groups for a batch of distributions.
 template <typename T, class Ctx>
 BFSM_HD void body_gen_plane_acc(const GenPlaneAccParams<T>& prm, Ctx& ctx) {
     const int nx = prm.nx, ny = prm.ny, nz = prm.nz;
