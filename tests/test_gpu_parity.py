@@ -1028,6 +1028,20 @@ def test_any_box_shards_batches_fp32_and_fft(torch_cuda, oracle):
     torch.cuda.synchronize()
     assert np.abs(Qb2[0].cpu().numpy() - ref).max() <= TOL64 * np.abs(ref).max()
     assert np.abs(Qb2[1].cpu().numpy() - 0.25 * ref).max() <= TOL64 * np.abs(ref).max()
+    # batch x direction shard (what a device of the multi-GPU operator runs): members go through the launches together,
+    # each rank's partial results add up to the whole, the loss term rides on rank 0; chunks of 7 directions, fp32 as well
+    for prec, tol in ((64, TOL64), (32, TOL32)):
+        parts = []
+        for r in range(2):
+            o2 = _make_box(bfsm, shape, n_gl, n_sph, precision=prec, shard=bfsm.shard_range(n_gl * n_sph, r, 2), max_chunk=7, max_batch=2)
+            Qp = torch.empty_like(fb)
+            o2.collideBatchPartial(Qp, fb, 2, r == 0)
+            torch.cuda.synchronize()
+            parts.append(Qp.cpu().numpy())
+            o2.destroy()
+        tot = parts[0] + parts[1]
+        assert np.abs(tot[0] - ref).max() <= tol * np.abs(ref).max()
+        assert np.abs(tot[1] - 0.25 * ref).max() <= tol * np.abs(ref).max()
     # transforms
     a = rng.standard_normal((2,) + shape) + 1j * rng.standard_normal((2,) + shape)
     d = torch.from_numpy(a).cuda()
