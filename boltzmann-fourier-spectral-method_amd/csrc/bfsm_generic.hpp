@@ -229,20 +229,20 @@ BFSM_HD void gen_stage_tw(cx<T>* dst, const cx<T>* tw, int n, Ctx& ctx) {
 }
 
 // FIRST: the pass with ns = 1, whose twiddles are all 1 (k = 0): no table reads, no multiplications.
-template <int R, bool NS_POW2, bool FIRST, typename T, class Ctx>
+template <int R, bool NS_POW2, bool FIRST, int C, typename T, class Ctx>
 BFSM_HD void gen_pass_impl(const cx<T>* src, cx<T>* dst, const cx<T>* tw, int n, int ns, int sgn, Ctx& ctx) {
     const int m = n / R;
-    const int col = ctx.tid() % GEN_C, row = ctx.tid() / GEN_C;
+    const int col = ctx.tid() % C, row = ctx.tid() / C;
     const int tstep = n / (ns * R);                    // twiddle exp(sgn 2 pi i k q / (ns R)) = tw[k q tstep], k q tstep < n
     const float inv_ns = 1.0f / (float)ns;
     const int sh = NS_POW2 ? (31 - __builtin_clz((unsigned)ns)) : 0;
-    for (int j = row; j < m; j += GEN_THREADS / GEN_C) {
+    for (int j = row; j < m; j += GEN_THREADS / C) {
         const int hi = NS_POW2 ? (j >> sh) : gen_div(j, inv_ns);
         const int k = NS_POW2 ? (j & (ns - 1)) : (j - hi * ns);   // position inside the sub-transform done so far
         cx<T> x[R];
 #pragma unroll
         for (int q = 0; q < R; ++q) {
-            x[q] = src[(j + q * m) * GEN_LS + col];
+            x[q] = src[(j + q * m) * (C + 1) + col];
             if (!FIRST && q > 0) {
                 const cx<T> w = tw[k * q * tstep];
                 x[q] = sgn < 0 ? cmul(x[q], w) : cmulc(x[q], w);
@@ -252,22 +252,22 @@ BFSM_HD void gen_pass_impl(const cx<T>* src, cx<T>* dst, const cx<T>* tw, int n,
         else gen_dft<R, T>(x, sgn);
         const int j0 = hi * ns * R + k;
 #pragma unroll
-        for (int q = 0; q < R; ++q) dst[(j0 + q * ns) * GEN_LS + col] = x[q];
+        for (int q = 0; q < R; ++q) dst[(j0 + q * ns) * (C + 1) + col] = x[q];
     }
 }
-template <int R, bool NS_POW2, typename T, class Ctx>
+template <int R, bool NS_POW2, int C, typename T, class Ctx>
 BFSM_HD void gen_pass(const cx<T>* src, cx<T>* dst, const cx<T>* tw, int n, int ns, int sgn, Ctx& ctx) {
     // (the twiddle-free instantiation pays in the plane kernels only: with it the x-line kernel measured 7 % slower)
-    gen_pass_impl<R, NS_POW2, false, T>(src, dst, tw, n, ns, sgn, ctx);
+    gen_pass_impl<R, NS_POW2, false, C, T>(src, dst, tw, n, ns, sgn, ctx);
 }
 
-// Batched 1-D transform along one axis.  grid = (blocks of GEN_C lines, batch).  Workgroup: GEN_THREADS threads, LDS =
-// two buffers of n x (GEN_C + 1) complex + the axis' n twiddles.  A "line" is the set of n points along the transformed axis; consecutive
+// Batched 1-D transform along one axis.  grid = (blocks of C lines, batch).  Workgroup: GEN_THREADS threads, LDS =
+// two buffers of n x (C + 1) complex + the axis' n twiddles.  A "line" is the set of n points along the transformed axis; consecutive
 // lines are consecutive in z (axes x, y) or consecutive (x, y) pairs (axis z).
 // BIG: the instantiation that also carries the table-driven radix-7 / 11 / 13 butterflies (13 complex inputs + 13 outputs
 // in registers: 256 VGPRs and a kilobyte of scratch per lane in double precision).  Axes whose factors are 2, 3, 5 only --
 // nearly every box -- run the instantiation without them (round 4; GK::Fft / GK::FftBig).
-template <typename T, bool BIG, class Ctx>
+template <typename T, bool BIG, int C, class Ctx>
 BFSM_HD void body_gen_fft(const GenFftParams<T>& prm, Ctx& ctx) {
     const int nx = prm.nx, ny = prm.ny, nz = prm.nz;
     const int axis = prm.axis;
@@ -283,15 +283,15 @@ BFSM_HD void body_gen_fft(const GenFftParams<T>& prm, Ctx& ctx) {
         out_moff = (size_t)m * prm.out_mstride;
     }
     cx<T>* buf0 = ctx.template lds<cx<T>>();
-    cx<T>* buf1 = buf0 + (size_t)n * GEN_LS;
-    cx<T>* twl = buf1 + (size_t)n * GEN_LS;
+    cx<T>* buf1 = buf0 + (size_t)n * (C + 1);
+    cx<T>* twl = buf1 + (size_t)n * (C + 1);
     gen_stage_tw<T>(twl, prm.tw, n, ctx);
-    // Global <-> LDS: lanes run along the contiguous (z) direction of memory.  Axes x, y: 16 consecutive lanes take
-    // the 16 lines of the block at one point; axis z: 16 consecutive lanes take 16 consecutive points of one line.
-    const int lane16 = ctx.tid() % GEN_C, grp = ctx.tid() / GEN_C;
-    const int cl = axis == 2 ? grp : lane16;           // line of the block this thread moves
-    const int p0 = axis == 2 ? lane16 : grp;           // first point; then steps of 16
-    const int col = ctx.bx() * GEN_C + cl;
+    // Global <-> LDS: lanes run along the contiguous (z) direction of memory.  Axes x, y: C consecutive lanes take the C
+    // lines of the block at one point; axis z: 256 / C consecutive lanes take as many consecutive points of one line.
+    constexpr int PW = GEN_THREADS / C;                // points covered per step
+    const int cl = axis == 2 ? ctx.tid() / PW : ctx.tid() % C;    // line of the block this thread moves
+    const int p0 = axis == 2 ? ctx.tid() % PW : ctx.tid() / C;    // first point; then steps of PW
+    const int col = ctx.bx() * C + cl;
     const bool live = col < ncols;
     // offset of point 0 of the line and the stride between its points; (ix, iy, iz) of point 0 for the fused factors
     size_t base = 0, ps = 1;
@@ -312,7 +312,7 @@ BFSM_HD void body_gen_fft(const GenFftParams<T>& prm, Ctx& ctx) {
     const cx<T>* inc = loss_slot ? prm.in2 : static_cast<const cx<T>*>(prm.in);
     // the global loads are issued four points at a time before any of them is consumed: the trip count is a run-time
     // value, and a rolled loop would pay one full memory latency per point
-    constexpr int STEP = GEN_THREADS / GEN_C, CH = 4;
+    constexpr int STEP = GEN_THREADS / C, CH = 4;
     for (int pc = p0; pc < n; pc += CH * STEP) {
         cx<T> vin[CH], vin2[CH];
 #pragma unroll
@@ -349,7 +349,7 @@ BFSM_HD void body_gen_fft(const GenFftParams<T>& prm, Ctx& ctx) {
                         }
                     }
                 }
-                buf0[pt * GEN_LS + cl] = v;
+                buf0[pt * (C + 1) + cl] = v;
             }
         }
     }
@@ -360,17 +360,17 @@ BFSM_HD void body_gen_fft(const GenFftParams<T>& prm, Ctx& ctx) {
     for (int r = 0; r < prm.n_radix; ++r) {
         const int R = prm.radix[r];
         const bool p2 = (ns & (ns - 1)) == 0;
-        if (R == 8) gen_pass<8, true, T>(src, dst, twl, n, ns, prm.sign, ctx);          // radices 8, 4, 2 come first
-        else if (R == 4) gen_pass<4, true, T>(src, dst, twl, n, ns, prm.sign, ctx);
-        else if (R == 2) gen_pass<2, true, T>(src, dst, twl, n, ns, prm.sign, ctx);
-        else if (R == 3 && p2) gen_pass<3, true, T>(src, dst, twl, n, ns, prm.sign, ctx);
-        else if (R == 3) gen_pass<3, false, T>(src, dst, twl, n, ns, prm.sign, ctx);
-        else if (R == 5 && p2) gen_pass<5, true, T>(src, dst, twl, n, ns, prm.sign, ctx);
-        else if (R == 5) gen_pass<5, false, T>(src, dst, twl, n, ns, prm.sign, ctx);
+        if (R == 8) gen_pass<8, true, C, T>(src, dst, twl, n, ns, prm.sign, ctx);          // radices 8, 4, 2 come first
+        else if (R == 4) gen_pass<4, true, C, T>(src, dst, twl, n, ns, prm.sign, ctx);
+        else if (R == 2) gen_pass<2, true, C, T>(src, dst, twl, n, ns, prm.sign, ctx);
+        else if (R == 3 && p2) gen_pass<3, true, C, T>(src, dst, twl, n, ns, prm.sign, ctx);
+        else if (R == 3) gen_pass<3, false, C, T>(src, dst, twl, n, ns, prm.sign, ctx);
+        else if (R == 5 && p2) gen_pass<5, true, C, T>(src, dst, twl, n, ns, prm.sign, ctx);
+        else if (R == 5) gen_pass<5, false, C, T>(src, dst, twl, n, ns, prm.sign, ctx);
         else if constexpr (BIG) {
-            if (R == 7) gen_pass<7, false, T>(src, dst, twl, n, ns, prm.sign, ctx);
-            else if (R == 11) gen_pass<11, false, T>(src, dst, twl, n, ns, prm.sign, ctx);
-            else gen_pass<13, false, T>(src, dst, twl, n, ns, prm.sign, ctx);
+            if (R == 7) gen_pass<7, false, C, T>(src, dst, twl, n, ns, prm.sign, ctx);
+            else if (R == 11) gen_pass<11, false, C, T>(src, dst, twl, n, ns, prm.sign, ctx);
+            else gen_pass<13, false, C, T>(src, dst, twl, n, ns, prm.sign, ctx);
         }
         ns *= R;
         ctx.sync();
@@ -378,7 +378,7 @@ BFSM_HD void body_gen_fft(const GenFftParams<T>& prm, Ctx& ctx) {
     }
     if (live) {
         const size_t out_off = out_moff + (size_t)b * prm.out_bstride;
-        for (int pt = p0; pt < n; pt += GEN_THREADS / GEN_C) prm.out[out_off + base + (size_t)pt * ps] = src[pt * GEN_LS + cl];
+        for (int pt = p0; pt < n; pt += GEN_THREADS / C) prm.out[out_off + base + (size_t)pt * ps] = src[pt * (C + 1) + cl];
     }
 }
 
@@ -506,20 +506,20 @@ BFSM_HD void body_gen_plane(const GenFftParams<T>& prm, Ctx& ctx) {
     }
 }
 
-// All Stockham passes of one axis over the GEN_C lines of a block held in LDS (the loop of body_gen_fft, radices 2..5)
-template <typename T, class Ctx>
+// All Stockham passes of one axis over the C lines of a block held in LDS (the loop of body_gen_fft, radices 2..5)
+template <typename T, int C, class Ctx>
 BFSM_HD void gen_line_axis(cx<T>*& src, cx<T>*& dst, const cx<T>* tw, const int* radix, int n_radix, int n, int sgn, Ctx& ctx) {
     int ns = 1;
     for (int r = 0; r < n_radix; ++r) {
         const int R = radix[r];
         const bool p2 = (ns & (ns - 1)) == 0;
-        if (R == 8) gen_pass<8, true, T>(src, dst, tw, n, ns, sgn, ctx);
-        else if (R == 4) gen_pass<4, true, T>(src, dst, tw, n, ns, sgn, ctx);
-        else if (R == 2) gen_pass<2, true, T>(src, dst, tw, n, ns, sgn, ctx);
-        else if (R == 3 && p2) gen_pass<3, true, T>(src, dst, tw, n, ns, sgn, ctx);
-        else if (R == 3) gen_pass<3, false, T>(src, dst, tw, n, ns, sgn, ctx);
-        else if (R == 5 && p2) gen_pass<5, true, T>(src, dst, tw, n, ns, sgn, ctx);
-        else gen_pass<5, false, T>(src, dst, tw, n, ns, sgn, ctx);
+        if (R == 8) gen_pass<8, true, C, T>(src, dst, tw, n, ns, sgn, ctx);
+        else if (R == 4) gen_pass<4, true, C, T>(src, dst, tw, n, ns, sgn, ctx);
+        else if (R == 2) gen_pass<2, true, C, T>(src, dst, tw, n, ns, sgn, ctx);
+        else if (R == 3 && p2) gen_pass<3, true, C, T>(src, dst, tw, n, ns, sgn, ctx);
+        else if (R == 3) gen_pass<3, false, C, T>(src, dst, tw, n, ns, sgn, ctx);
+        else if (R == 5 && p2) gen_pass<5, true, C, T>(src, dst, tw, n, ns, sgn, ctx);
+        else gen_pass<5, false, C, T>(src, dst, tw, n, ns, sgn, ctx);
         ns *= R;
         ctx.sync();
         cx<T>* t = src; src = dst; dst = t;
@@ -527,24 +527,24 @@ BFSM_HD void gen_line_axis(cx<T>*& src, cx<T>*& dst, const cx<T>* tw, const int*
 }
 
 // x-lines of one direction: A1 = IFFT_x(A1'), A2 = IFFT_x(A2'), P = A1 * A2 (hadamard_product, Kernels.cu:62-74),
-// P' = FFT_x(P), written over A1' -- what KB does on the cubes.  grid = (blocks of GEN_C lines, directions); LDS = three
-// buffers of nx x (GEN_C + 1): the second transform ping-pongs between the third buffer and the one the first left free.
-template <typename T, class Ctx>
+// P' = FFT_x(P), written over A1' -- what KB does on the cubes.  grid = (blocks of C lines, directions); LDS = three
+// buffers of nx x (C + 1): the second transform ping-pongs between the third buffer and the one the first left free.
+template <typename T, int C, class Ctx>
 BFSM_HD void body_gen_line3(const GenLineParams<T>& prm, Ctx& ctx) {
     const int n = prm.nx;
     const size_t ps = (size_t)prm.ny * prm.nz, G = ps * (size_t)n;
     cx<T>* X = ctx.template lds<cx<T>>();
-    cx<T>* Y = X + (size_t)n * GEN_LS;
-    cx<T>* Z = Y + (size_t)n * GEN_LS;
-    cx<T>* twl = Z + (size_t)n * GEN_LS;
+    cx<T>* Y = X + (size_t)n * (C + 1);
+    cx<T>* Z = Y + (size_t)n * (C + 1);
+    cx<T>* twl = Z + (size_t)n * (C + 1);
     gen_stage_tw<T>(twl, prm.tw, n, ctx);
-    const int cl = ctx.tid() % GEN_C, p0 = ctx.tid() / GEN_C;
-    const size_t col = (size_t)ctx.bx() * GEN_C + cl;
+    const int cl = ctx.tid() % C, p0 = ctx.tid() / C;
+    const size_t col = (size_t)ctx.bx() * C + cl;
     const bool live = col < ps;
     const int mem = ctx.by() / prm.n, dl = ctx.by() - mem * prm.n;
     cx<T>* A1 = prm.a + (size_t)mem * prm.mstride + (size_t)dl * 2 * G + col;
     const cx<T>* A2 = A1 + G;
-    constexpr int STEP = GEN_THREADS / GEN_C, CH = 4;
+    constexpr int STEP = GEN_THREADS / C, CH = 4;
     for (int pc = p0; pc < n; pc += CH * STEP) {
         cx<T> v1[CH], v2[CH];
 #pragma unroll
@@ -557,23 +557,23 @@ BFSM_HD void body_gen_line3(const GenLineParams<T>& prm, Ctx& ctx) {
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
             const int pt = pc + i * STEP;
-            if (pt < n) { X[pt * GEN_LS + cl] = v1[i]; Z[pt * GEN_LS + cl] = v2[i]; }
+            if (pt < n) { X[pt * (C + 1) + cl] = v1[i]; Z[pt * (C + 1) + cl] = v2[i]; }
         }
     }
     ctx.sync();
     cx<T>* src = X;
     cx<T>* dst = Y;
-    gen_line_axis<T>(src, dst, twl, prm.radix, prm.n_radix, n, +1, ctx);
+    gen_line_axis<T, C>(src, dst, twl, prm.radix, prm.n_radix, n, +1, ctx);
     cx<T>* r1 = src;                         // A1 along x; dst is free
     src = Z;
-    gen_line_axis<T>(src, dst, twl, prm.radix, prm.n_radix, n, +1, ctx);
-    for (int pt = p0; pt < n; pt += STEP) r1[pt * GEN_LS + cl] = cmul(r1[pt * GEN_LS + cl], src[pt * GEN_LS + cl]);
+    gen_line_axis<T, C>(src, dst, twl, prm.radix, prm.n_radix, n, +1, ctx);
+    for (int pt = p0; pt < n; pt += STEP) r1[pt * (C + 1) + cl] = cmul(r1[pt * (C + 1) + cl], src[pt * (C + 1) + cl]);
     ctx.sync();
     dst = src;                               // A2 is consumed: its buffer is the forward transform's second one
     src = r1;
-    gen_line_axis<T>(src, dst, twl, prm.radix, prm.n_radix, n, -1, ctx);
+    gen_line_axis<T, C>(src, dst, twl, prm.radix, prm.n_radix, n, -1, ctx);
     if (live)
-        for (int pt = p0; pt < n; pt += STEP) A1[(size_t)pt * ps] = src[pt * GEN_LS + cl];
+        for (int pt = p0; pt < n; pt += STEP) A1[(size_t)pt * ps] = src[pt * (C + 1) + cl];
 }
 
 // KA of the cubes in size-generic form: the phase multiply (compute_alpha_times_f_hat, Kernels.cu:21-59) and the (y,z) part
@@ -788,7 +788,7 @@ BFSM_HD void body_gen_combine(const GenCombineParams<T>& prm, Ctx& ctx) {
     prm.Q[idx] = q;
 }
 
-enum class GK { Fft, Acc, Combine, FftBig, Plane, Line3, PlaneAcc, PlanePair };   // FftBig: Fft + the radix-7 / 11 / 13 passes; Plane: y and z
+enum class GK { Fft, Acc, Combine, FftBig, Plane, Line3, PlaneAcc, PlanePair, Fft8, FftBig8, Line38 };   // ...8: 8 lines per workgroup   // FftBig: Fft + the radix-7 / 11 / 13 passes; Plane: y and z
                                                                       // pass fused; Line3 / PlaneAcc: the fused sequence
 
 inline bool gen_factor(int n, std::vector<int>& radix) {
@@ -983,7 +983,9 @@ struct GenericPipeline {
         p.nx = nx; p.ny = ny; p.nz = nz; p.axis = axis; p.sign = sign;
         const int n = axis_len(axis);
         const int ncols = (int)(G / (size_t)n);
-        const int C = GEN_C;
+        // 16 lines per workgroup, 8 where 16 would leave one workgroup per CU (two line buffers above 80 KB: n > 147 in
+        // double precision) -- 128-byte instead of 256-byte runs, but three workgroups per CU instead of one
+        const int C = pass_lines(n);
         p.C = C;
         p.n_radix = (int)radix[axis].size();
         for (int i = 0; i < p.n_radix; ++i) p.radix[i] = radix[axis][i];
@@ -992,8 +994,25 @@ struct GenericPipeline {
         const size_t lds = ((size_t)2 * n * (C + 1) + n) * sizeof(cx<T>);
         bool big = false;
         for (int r : radix[axis]) big = big || gen_table_radix(r);
-        if (big) be->template launch_gen<GK::FftBig, T>((ncols + C - 1) / C, batch, GEN_THREADS, lds, p);
+        if (big && C == 8) be->template launch_gen<GK::FftBig8, T>((ncols + C - 1) / C, batch, GEN_THREADS, lds, p);
+        else if (big) be->template launch_gen<GK::FftBig, T>((ncols + C - 1) / C, batch, GEN_THREADS, lds, p);
+        else if (C == 8) be->template launch_gen<GK::Fft8, T>((ncols + C - 1) / C, batch, GEN_THREADS, lds, p);
         else be->template launch_gen<GK::Fft, T>((ncols + C - 1) / C, batch, GEN_THREADS, lds, p);
+    }
+    int pass_lines(int n) const {
+#ifdef BFSM_GEN_LINES16           // A/B builds (tools only)
+        return GEN_C;
+#else
+        return ((size_t)2 * n * (GEN_C + 1) + n) * sizeof(cx<T>) > (size_t)80 * 1024 ? 8 : GEN_C;
+#endif
+    }
+    // ... and the x-line kernel with its three buffers
+    int line3_lines() const {
+#ifdef BFSM_GEN_LINES16
+        return GEN_C;
+#else
+        return ((size_t)3 * nx * (GEN_C + 1) + nx) * sizeof(cx<T>) > (size_t)80 * 1024 ? 8 : GEN_C;
+#endif
     }
 
     // the fused (y,z) plane kernel serves boxes whose plane fits the LDS twice and whose y / z factors are 2, 3, 5
@@ -1042,7 +1061,7 @@ struct GenericPipeline {
         return false;
 #else
         for (int r : radix[0]) if (gen_table_radix(r)) return false;
-        return ((size_t)3 * nx * GEN_LS + nx) * sizeof(cx<T>) <= lds_cap;
+        return ((size_t)3 * nx * (line3_lines() + 1) + nx) * sizeof(cx<T>) <= lds_cap;
 #endif
     }
     void line3(const Chunk& c, int nb = 1) {
@@ -1053,7 +1072,10 @@ struct GenericPipeline {
         for (int i = 0; i < kl.n_radix; ++i) kl.radix[i] = radix[0][i];
         const int ncols = ny * nz;
         be->mark(BFSM_K_GAIN_LINE, 3.0 * c.n * nb * (double)G * sizeof(cx<T>));
-        be->template launch_gen<GK::Line3, T>((ncols + GEN_C - 1) / GEN_C, c.n * nb, GEN_THREADS, ((size_t)3 * nx * GEN_LS + nx) * sizeof(cx<T>), kl);
+        const int C = line3_lines();
+        const size_t lds = ((size_t)3 * nx * (C + 1) + nx) * sizeof(cx<T>);
+        if (C == 8) be->template launch_gen<GK::Line38, T>((ncols + C - 1) / C, c.n * nb, GEN_THREADS, lds, kl);
+        else be->template launch_gen<GK::Line3, T>((ncols + C - 1) / C, c.n * nb, GEN_THREADS, lds, kl);
     }
     // groups of directions per x-plane in the plane-accumulate kernel: about a thousand workgroups per launch
     int groups_for(int n) const {

@@ -384,14 +384,17 @@ template <GK kind, typename T, class P>
 __global__ void __launch_bounds__(GEN_THREADS) bfsm_gen_kernel(const P prm) {
     extern __shared__ __align__(16) unsigned char bfsm_smem[];
     DevCtx ctx{bfsm_smem};
-    if constexpr (kind == GK::Fft) body_gen_fft<T, false>(prm, ctx);
-    else if constexpr (kind == GK::FftBig) body_gen_fft<T, true>(prm, ctx);
+    if constexpr (kind == GK::Fft) body_gen_fft<T, false, GEN_C>(prm, ctx);
+    else if constexpr (kind == GK::FftBig) body_gen_fft<T, true, GEN_C>(prm, ctx);
     else if constexpr (kind == GK::Plane) body_gen_plane<T>(prm, ctx);
     else if constexpr (kind == GK::Acc) body_gen_acc<T>(prm, ctx);
     else if constexpr (kind == GK::Combine) body_gen_combine<T>(prm, ctx);
-    else if constexpr (kind == GK::Line3) body_gen_line3<T>(prm, ctx);
+    else if constexpr (kind == GK::Line3) body_gen_line3<T, GEN_C>(prm, ctx);
     else if constexpr (kind == GK::PlaneAcc) body_gen_plane_acc<T>(prm, ctx);
     else if constexpr (kind == GK::PlanePair) body_gen_plane_pair<T>(prm, ctx);
+    else if constexpr (kind == GK::Fft8) body_gen_fft<T, false, 8>(prm, ctx);
+    else if constexpr (kind == GK::FftBig8) body_gen_fft<T, true, 8>(prm, ctx);
+    else if constexpr (kind == GK::Line38) body_gen_line3<T, 8>(prm, ctx);
 }
 
 // N = 16 whole-direction kernels: 256 threads, two padded cubes of LDS

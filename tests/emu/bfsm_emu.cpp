@@ -245,14 +245,17 @@ struct EmuBackend {
     template <bfsm::GK kind, typename T, class P>
     static void body_gen(void* a, EmuCtx& ctx) {
         const P& prm = *static_cast<const P*>(a);
-        if constexpr (kind == bfsm::GK::Fft) bfsm::body_gen_fft<T, false>(prm, ctx);
-    else if constexpr (kind == bfsm::GK::FftBig) bfsm::body_gen_fft<T, true>(prm, ctx);
+        if constexpr (kind == bfsm::GK::Fft) bfsm::body_gen_fft<T, false, bfsm::GEN_C>(prm, ctx);
+    else if constexpr (kind == bfsm::GK::FftBig) bfsm::body_gen_fft<T, true, bfsm::GEN_C>(prm, ctx);
     else if constexpr (kind == bfsm::GK::Plane) bfsm::body_gen_plane<T>(prm, ctx);
         else if constexpr (kind == bfsm::GK::Acc) bfsm::body_gen_acc<T>(prm, ctx);
         else if constexpr (kind == bfsm::GK::Combine) bfsm::body_gen_combine<T>(prm, ctx);
-        else if constexpr (kind == bfsm::GK::Line3) bfsm::body_gen_line3<T>(prm, ctx);
+        else if constexpr (kind == bfsm::GK::Line3) bfsm::body_gen_line3<T, bfsm::GEN_C>(prm, ctx);
         else if constexpr (kind == bfsm::GK::PlaneAcc) bfsm::body_gen_plane_acc<T>(prm, ctx);
         else if constexpr (kind == bfsm::GK::PlanePair) bfsm::body_gen_plane_pair<T>(prm, ctx);
+        else if constexpr (kind == bfsm::GK::Fft8) bfsm::body_gen_fft<T, false, 8>(prm, ctx);
+        else if constexpr (kind == bfsm::GK::FftBig8) bfsm::body_gen_fft<T, true, 8>(prm, ctx);
+        else if constexpr (kind == bfsm::GK::Line38) bfsm::body_gen_line3<T, 8>(prm, ctx);
     }
 
     template <bfsm::GK kind, typename T, class P>

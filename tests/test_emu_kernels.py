@@ -355,7 +355,10 @@ def test_randomised_plans_against_the_oracle(oracle):
     ((16, 8, 6), 5, 6, 64, 1e-12, {}),                       # fused sequence: groups of 15 directions across radial nodes
     ((12, 6, 10), 4, 6, 32, 2e-5, {"max_chunk": 17}),        # ... single precision, ragged chunks
     ((8, 14, 6), 2, 6, 64, 1e-12, {}),                       # x-line kernel between per-axis passes (a radix-7 y axis: no plane kernel)
-    ((100, 4, 6), 1, 6, 64, 1e-12, {}),                      # x-line kernel between plane kernels (x lines too long for the fused sequence)
+    ((100, 4, 6), 1, 6, 64, 1e-12, {}),                      # 100-point x lines (three 16-line buffers still fit)
+    ((160, 4, 6), 1, 6, 64, 1e-12, {}),                      # long x lines: 8 lines per workgroup in the x passes and the x-line kernel
+    ((4, 14, 160), 1, 6, 64, 1e-12, {}),                     # ... in a z pass (no plane kernel: radix-7 y axis)
+    ((154, 4, 4), 1, 6, 64, 1e-12, {}),                      # ... with the table-driven radices (154 = 2 x 7 x 11)
     ((8, 16, 4), 2, 6, 32, 2e-5, {}),                        # single-precision variant
     ((14, 22, 26), 2, 6, 64, 1e-12, {}),                     # radices 7, 11, 13 (table-driven butterflies)
     ((28, 6, 4), 2, 6, 64, 1e-12, {}),                       # 7 behind 4
