@@ -91,8 +91,9 @@ typedef struct bfsm_desc {
     int nvx, nvy, nvz;        /* velocity grid: every extent even, in [4, 256], prime factors 2, 3, 5, 7, 11, 13 (the
                                  reference plans any Nvx x Nvy x Nvz, CUDABoltzmannOperator.cu:86-100).  Cubes of 16, 24, 32,
                                  40, 48, 64, 80, 96, 128 run on the fused pipeline (6 array passes per direction); every other box
-                                 on the size-generic path (one transform pass per axis, several times slower), both
-                                 precisions.  Anything else: BFSM_ERR_UNSUPPORTED */
+                                 on the size-generic path (run-time sizes: the same three fused kernels where a (y,z) plane
+                                 fits the LDS, per-axis passes otherwise; a half to a sixth of the fused pipeline's speed),
+                                 both precisions.  Anything else: BFSM_ERR_UNSUPPORTED */
     int n_gl;                 /* Gauss-Legendre points (radial)          */
     int n_sph;                /* spherical quadrature points             */
     const double* gl_nodes;   /* [n_gl]  rho_r on [0,R]                   */
