@@ -537,7 +537,7 @@ BFSM_HD void body_gen_line3(const GenLineParams<T>& prm, Ctx& ctx) {
     cx<T>* Y = X + (size_t)n * (C + 1);
     cx<T>* Z = Y + (size_t)n * (C + 1);
     cx<T>* twl = Z + (size_t)n * (C + 1);
-    gen_stage_tw<T>(twl, prm.tw, n, ctx);
+    if constexpr (C != 8) gen_stage_tw<T>(twl, prm.tw, n, ctx);      // (the 8-line form has its own layout, below)
     const int cl = ctx.tid() % C, p0 = ctx.tid() / C;
     const size_t col = (size_t)ctx.bx() * C + cl;
     const bool live = col < ps;
@@ -545,6 +545,56 @@ BFSM_HD void body_gen_line3(const GenLineParams<T>& prm, Ctx& ctx) {
     cx<T>* A1 = prm.a + (size_t)mem * prm.mstride + (size_t)dl * 2 * G + col;
     const cx<T>* A2 = A1 + G;
     constexpr int STEP = GEN_THREADS / C, CH = 4;
+    if constexpr (C == 8) {
+        // Long lines (the 8-line form): TWO buffers.  A thread owns n / 32 <= 8 points of its line; A2' waits in registers while
+        // A1' is transformed, the transformed A1 waits in registers while A2' is: 49 KB instead of 72 KB of LDS at n = 160,
+        // three workgroups per CU instead of two.
+        constexpr int K = GEN_MAX_N / STEP;
+        cx<T> k1[K], k2[K];
+        cx<T>* Yb = X + (size_t)n * (C + 1);
+        cx<T>* tw2 = Yb + (size_t)n * (C + 1);
+        gen_stage_tw<T>(tw2, prm.tw, n, ctx);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int pt = p0 + k * STEP;
+            k1[k] = {(T)0, (T)0};
+            k2[k] = {(T)0, (T)0};
+            if (live && pt < n) { k1[k] = A1[(size_t)pt * ps]; k2[k] = A2[(size_t)pt * ps]; }
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int pt = p0 + k * STEP;
+            if (pt < n) X[pt * (C + 1) + cl] = k1[k];
+        }
+        ctx.sync();
+        cx<T>* src = X;
+        cx<T>* dst = Yb;
+        gen_line_axis<T, C>(src, dst, tw2, prm.radix, prm.n_radix, n, +1, ctx);
+        // own points of the transformed A1 into registers, A2' into the OTHER buffer (nobody reads it now), then transform it
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int pt = p0 + k * STEP;
+            if (pt < n) { k1[k] = src[pt * (C + 1) + cl]; dst[pt * (C + 1) + cl] = k2[k]; }
+        }
+        ctx.sync();
+        { cx<T>* t = src; src = dst; dst = t; }
+        gen_line_axis<T, C>(src, dst, tw2, prm.radix, prm.n_radix, n, +1, ctx);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int pt = p0 + k * STEP;
+            if (pt < n) src[pt * (C + 1) + cl] = cmul(k1[k], src[pt * (C + 1) + cl]);
+        }
+        ctx.sync();
+        gen_line_axis<T, C>(src, dst, tw2, prm.radix, prm.n_radix, n, -1, ctx);
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int pt = p0 + k * STEP;
+                if (pt < n) A1[(size_t)pt * ps] = src[pt * (C + 1) + cl];
+            }
+        }
+        return;
+    }
     for (int pc = p0; pc < n; pc += CH * STEP) {
         cx<T> v1[CH], v2[CH];
 #pragma unroll
@@ -1061,8 +1111,13 @@ struct GenericPipeline {
         return false;
 #else
         for (int r : radix[0]) if (gen_table_radix(r)) return false;
-        return ((size_t)3 * nx * (line3_lines() + 1) + nx) * sizeof(cx<T>) <= lds_cap;
+        return line3_lds() <= lds_cap;
 #endif
+    }
+    // LDS of the x-line kernel: three line buffers, two in the 8-line form (which parks a line in registers instead)
+    size_t line3_lds() const {
+        const int C = line3_lines();
+        return ((size_t)(C == 8 ? 2 : 3) * nx * (C + 1) + nx) * sizeof(cx<T>);
     }
     void line3(const Chunk& c, int nb = 1) {
         GenLineParams<T> kl{};
@@ -1073,7 +1128,7 @@ struct GenericPipeline {
         const int ncols = ny * nz;
         be->mark(BFSM_K_GAIN_LINE, 3.0 * c.n * nb * (double)G * sizeof(cx<T>));
         const int C = line3_lines();
-        const size_t lds = ((size_t)3 * nx * (C + 1) + nx) * sizeof(cx<T>);
+        const size_t lds = line3_lds();
         if (C == 8) be->template launch_gen<GK::Line38, T>((ncols + C - 1) / C, c.n * nb, GEN_THREADS, lds, kl);
         else be->template launch_gen<GK::Line3, T>((ncols + C - 1) / C, c.n * nb, GEN_THREADS, lds, kl);
     }
