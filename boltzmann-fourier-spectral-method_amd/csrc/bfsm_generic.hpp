@@ -1132,12 +1132,13 @@ struct GenericPipeline {
         if (C == 8) be->template launch_gen<GK::Line38, T>((ncols + C - 1) / C, c.n * nb, GEN_THREADS, lds, kl);
         else be->template launch_gen<GK::Line3, T>((ncols + C - 1) / C, c.n * nb, GEN_THREADS, lds, kl);
     }
-    // groups of directions per x-plane in the plane-accumulate kernel: about a thousand workgroups per launch
+    // groups of directions per x-plane in the plane-accumulate kernel: about 512 workgroups per launch (two per CU; 1024 and
+    // 2048 measured 3 % and 7 % slower over the evaluation at 32 x 64 x 16: more slabs to write and to sum)
     int groups_for(int n) const {
 #ifdef BFSM_GEN_TARGET_WGS        // the emulator build asks for few workgroups, so that its small cases give a group several
         int g = (BFSM_GEN_TARGET_WGS + nx - 1) / nx;          // directions and runs that cross radial nodes
 #else
-        int g = (1024 + nx - 1) / nx;
+        int g = (512 + nx - 1) / nx;
 #endif
         if (g > n) g = n;
         if (g < 1) g = 1;
